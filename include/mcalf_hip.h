@@ -1,0 +1,143 @@
+/* mcalf_hip.h -- C ABI of libmcalf_hip.so: the MI355X (gfx950) implementation of the
+ * MC-ALF likelihood hot path (Voigt synthesis -> exp(-tau) -> Gaussian-LSF convolution
+ * -> Gaussian log-likelihood) for a batch of live points.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, never throws, and
+ * returns 0 (MCALF_OK) or a negative MCALF_ERR_* code; the message is available from
+ * mcalf_last_error().  Per-sample numerical failures are VALUES in the output
+ * (nan / -inf), not errors -- as in the reference, where invalid models surface through
+ * np.nansum (hires_fitter.py:294).
+ *
+ * Reference interfaces replaced (paths relative to /root/reference/mcalf/routines/):
+ *   mcalf_create           <- als_fitter.__init__ data/layout state   hires_fitter.py:32-200
+ *   mcalf_loglike_batch    <- als_fitter.lnlhood_worker (per row)     hires_fitter.py:287-328
+ *                             (and the closure of get_jax_likelihood  hires_fitter.py:685-693
+ *                              when conv_mode = MCALF_CONV_SAME_EDGE_JAX)
+ *   mcalf_model_batch      <- als_fitter.reconstruct_spec(p,targonly) hires_fitter.py:409-449
+ *   mcalf_onecomp_batch    <- reconstruct_onecomp / _onecomp_fill     hires_fitter.py:379-406
+ *   mcalf_chi2_batch       <- als_fitter.chi2                         hires_fitter.py:236-248
+ *   mcalf_scale_cube_batch <- _scale_cube_pc / _scale_cube_mn         hires_fitter.py:202-216
+ *   mcalf_voigt_hjerting   <- scipy.special.wofz(u + i a).real        hires_fitter.py:365
+ *                             / voigt_jax.hjert                       voigt_jax.py:121-127
+ *
+ * Ownership: the context owns all device memory it allocates.  Host pointers passed to
+ * any call are borrowed for the duration of that call only.  `*_device` entries take
+ * DEVICE pointers valid on the context's GPU and enqueue on the given hipStream_t
+ * (passed as void*; NULL = the legacy default stream) without synchronising.
+ *
+ * Threading: a context is not re-entrant (one in-flight call per context); distinct
+ * contexts are independent.
+ */
+#ifndef MCALF_HIP_H
+#define MCALF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCALF_ABI_VERSION 1
+
+enum {
+    MCALF_OK = 0,
+    MCALF_ERR_INVALID = -1,   /* bad argument / inconsistent spec          */
+    MCALF_ERR_HIP = -2,       /* a HIP runtime call failed                 */
+    MCALF_ERR_NODEVICE = -3,  /* no usable gfx950 device                   */
+    MCALF_ERR_RANGE = -4,     /* problem exceeds a build-time capacity     */
+    MCALF_ERR_NOMEM = -5
+};
+
+enum {
+    MCALF_CONV_WRAP_NUMPY = 0,    /* numpy path: periodic boundary, per-sample kernel length,
+                                     convolution skipped when R <= velstep (hires_fitter.py:445-464) */
+    MCALF_CONV_SAME_EDGE_JAX = 1  /* JAX path: fixed kernel grid from max specres, zero padding,
+                                     edges reset to the unconvolved model, always convolved,
+                                     floor() on the ncomp slot (hires_fitter.py:549-560,616,667-681) */
+};
+
+typedef struct mcalf_ctx mcalf_ctx;
+
+/* One transition: rest wavelength [Angstrom], oscillator strength, damping gamma [1/s]. */
+typedef struct {
+    double wrest_A;
+    double f;
+    double gamma;
+} mcalf_line;
+
+/* Problem definition: what als_fitter.__init__ leaves in `self` for the likelihood to read. */
+typedef struct {
+    int64_t npix;            /* number of selected pixels                                    */
+    const double* wl;        /* [npix] obj_wl, Angstrom            (host, copied)            */
+    const double* flux;      /* [npix] obj                         (host, copied)            */
+    const double* err;       /* [npix] obj_noise                   (host, copied)            */
+    double velstep;          /* km/s per pixel (hires_fitter.py:84-87)                       */
+    int32_t nlines;          /* numlines                                                     */
+    const mcalf_line* lines; /* [nlines] linepars                  (host, copied)            */
+    mcalf_line fill;         /* linefill (hires_fitter.py:120-121)                           */
+    int32_t ncompmax;        /* upper bound of the ncomp slot                                */
+    int32_t nfill;           /* number of filler components                                  */
+    int32_t freespecres;     /* 1: p[0] is the LSF FWHM                                      */
+    int32_t freecont;        /* 1: continuum is a free parameter                             */
+    double specres_fixed;    /* FWHM km/s used when !freespecres: max(specres) for the numpy
+                                path, specres[0] for the JAX path                            */
+    double specres_max;      /* largest FWHM any sample may carry (sizes the LDS halo and the
+                                fixed JAX kernel grid)                                       */
+    double contval_fixed;    /* continuum when !freecont                                     */
+    int32_t conv_mode;       /* MCALF_CONV_*                                                 */
+    int32_t device;          /* HIP device ordinal, or -1 for the current device             */
+} mcalf_spec;
+
+typedef struct {
+    int32_t abi_version;
+    int32_t ndim;       /* [freespecres] + [freecont] + 1 + 3*ncompmax + 3*nfill             */
+    int32_t startind;   /* index of the ncomp slot      (hires_fitter.py:169-174)            */
+    int32_t endind;     /* first filler parameter       (hires_fitter.py:176)                */
+    int32_t n_cap;      /* LSF half-width (pixels) provisioned from specres_max              */
+    int32_t tile;       /* pixels per workgroup tile                                         */
+    int32_t ntiles;     /* tiles per sample                                                  */
+    int32_t device;     /* HIP device ordinal in use                                         */
+    int64_t npix;
+    char arch[32];      /* gcnArchName of the device                                         */
+} mcalf_info_t;
+
+/* Create / destroy.  mcalf_create never returns a half-built context: on failure *out is
+ * NULL and mcalf_last_error(NULL) holds the message. */
+int mcalf_create(const mcalf_spec* spec, mcalf_ctx** out);
+void mcalf_destroy(mcalf_ctx* ctx);
+int mcalf_info(const mcalf_ctx* ctx, mcalf_info_t* info);
+const char* mcalf_last_error(const mcalf_ctx* ctx);
+const char* mcalf_version(void);
+
+/* Pre-size the context's device workspaces for batches up to `batch` rows so that later
+ * calls (including *_device calls captured into a hipGraph) allocate nothing. */
+int mcalf_reserve(mcalf_ctx* ctx, int64_t batch);
+
+/* logL[i] = lnlhood_worker(P[i, :]) for i < batch.   P row-major [batch][ndim], host. */
+int mcalf_loglike_batch(mcalf_ctx* ctx, const double* P, int64_t batch, double* logL);
+/* flux[i, :] = reconstruct_spec(P[i, :], targonly).  flux row-major [batch][npix], host. */
+int mcalf_model_batch(mcalf_ctx* ctx, const double* P, int64_t batch, int32_t targonly, double* flux);
+/* chi2[i] = nansum(ispec2 (obj - model)^2); +inf when the model is identically zero. */
+int mcalf_chi2_batch(mcalf_ctx* ctx, const double* P, int64_t batch, double* chi2);
+/* Single-component spectra: rows of Q are (R, cont, N, z, b); fill != 0 uses the filler line. */
+int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batch, int32_t fill, double* flux);
+
+/* Same, device pointers + stream, asynchronous. */
+int mcalf_loglike_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, double* dlogL, void* stream);
+int mcalf_model_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, int32_t targonly,
+                             double* dflux, void* stream);
+
+/* Prior transform: theta = cube * ptp(bounds) + min(bounds) per dimension; when
+ * int_ncomp != 0 the ncomp slot is truncated like Python int() (_scale_cube_pc), otherwise
+ * left as is (_scale_cube_mn).  lo/hi are [ndim] host arrays; cube/theta [batch][ndim] host. */
+int mcalf_scale_cube_batch(mcalf_ctx* ctx, const double* lo, const double* hi, const double* cube,
+                           int64_t batch, int32_t int_ncomp, double* theta);
+
+/* Diagnostic: out[i] = H(x[i], y[i]) = Re w(x + i y) evaluated by the device Voigt function
+ * (host pointers).  device = -1 for the current device. */
+int mcalf_voigt_hjerting(const double* x, const double* y, int64_t n, double* out, int32_t device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCALF_HIP_H */

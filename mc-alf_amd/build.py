@@ -1,0 +1,39 @@
+"""Build libmcalf_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+SOURCES = ["mcalf_hip.hip"]
+HEADERS = ["voigt_device.h", "voigt_tables.h", os.path.join("..", "..", "include", "mcalf_hip.h")]
+TARGET = os.path.join(CSRC, "libmcalf_hip.so")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
+
+
+def _stale():
+    if not os.path.exists(TARGET):
+        return True
+    t = os.path.getmtime(TARGET)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP library if it is missing or older than its sources."""
+    if not force and not _stale():
+        return TARGET
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + FLAGS + ["-o", TARGET] + SOURCES
+    if verbose:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    if verbose:
+        print(res.stderr)
+    return TARGET
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,687 @@
+// libmcalf_hip.so -- MI355X (gfx950) implementation of the MC-ALF likelihood hot path.
+//
+// One fused kernel per call: for a workgroup = (live point s, pixel tile T)
+//   1. decode p_s, build per-(component,line) constants in LDS     hires_fitter.py:412-431,357-364
+//   2. tau(pixel) = sum_cl K_cl H(u_cl(pixel), a_cl); flux = exp(-tau) -> LDS tile with +-n halo
+//                                                                   hires_fitter.py:365,377,430-442
+//   3. sliding-window Gaussian LSF from LDS (periodic / zero-pad)   hires_fitter.py:452-464 / :667-681
+//   4. x continuum, Gaussian log-likelihood terms, nansum, wave+LDS reduce
+//                                                                   hires_fitter.py:292-294
+// and a tiny second kernel that adds the per-tile partials in fixed order (deterministic: no
+// float atomics, so a sharded batch equals the unsharded one bit for bit).
+//
+// The C ABI is declared in include/mcalf_hip.h.  There is no CPU fallback: every entry point
+// fails with MCALF_ERR_NODEVICE when no gfx950 device is present.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mcalf_hip.h"
+#include "voigt_device.h"
+
+namespace mcalf {
+
+constexpr int kBlock = 256;
+constexpr int kClStride = 8;            // doubles per (component,line) record in LDS
+constexpr int kExtDefault = 4096;       // pixels (tile + halo) per workgroup: 32 KiB of LDS
+constexpr size_t kLdsBudget = 64 * 1024;
+constexpr double kCcgs = 2.9979245e10;  // hires_fitter.py:66
+constexpr double kFwhmToSigma = 2.354820;   // hires_fitter.py:454
+constexpr double kKernelReach = 3.0348;     // hires_fitter.py:458
+constexpr double kTauConst = 0.014971475;   // hires_fitter.py:364
+
+enum Mode : int { kModeLogL = 0, kModeModel = 1, kModeChi2 = 2, kModeOneComp = 3 };
+
+struct LineDev {
+    double wrest_cm;  // wrest/1e8                 hires_fitter.py:376
+    double f;
+    double gamma;
+    double nujk;      // ccgs / wrest_cm           hires_fitter.py:359
+};
+
+struct KArgs {
+    const double* nu;       // [npix] ccgs / (wl/1e8): pixel frequency at z = 0
+    const double* obj;      // [npix]
+    const double* ispec2;   // [npix] 1/err^2
+    const double* lgis;     // [npix] log(ispec2)
+    const double* P;        // [batch][ndim]  (mode OneComp: [batch][5])
+    double* partial;        // [batch][ntiles][2]  (sum, nonzero-count)
+    double* out;            // logL / chi2 [batch]   (written directly when ntiles == 1)
+    double* model;          // [batch][npix] or nullptr
+    const LineDev* lines;   // [nlines] then the filler line at [nlines]
+    const double* tabs;     // VT_L (384) then VT_K1 (384)
+    int npix, ndim, ntiles, tile, n_cap, ncl_cap;
+    int nlines, ncompmax, nfill, startind, endind, freespecres, freecont, conv_mode;
+    int targonly, mode, jax_half, onecomp_fill;
+    double specres_fixed, contval_fixed, velstep, log2pi;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double finalize_value(int mode, double sum, double nnz) {
+    if (mode == kModeChi2) return (nnz == 0.0) ? INFINITY : sum;   // hires_fitter.py:241-246
+    return -0.5 * sum;                                             // hires_fitter.py:294
+}
+
+// Record layout per (component,line): [A, B, y2, Kyt, y, ey2, K, flag]
+//   u = nu*A - B;  wing: tau += Kyt * t*(M1 - q(M3 - q M5));  core: tau += K * H_core(x, y)
+__device__ inline void build_line_record(double* rec, double logN, double z, double b_kms, const LineDev& ln) {
+    const double cold = pow(10.0, logN);                 // :357
+    const double zp1 = z + 1.0;                          // :358
+    const double dnu = (b_kms * 1e5) / ln.wrest_cm;      // :360 with :376's b*1e5
+    const double a = ln.gamma / (4.0 * M_PI * dnu);      // :361
+    const double cne = kTauConst * cold * ln.f;          // :364
+    const double K = cne / dnu;                          // :365  tau = cne * H / dnu
+    rec[0] = zp1 / dnu;                                  // u = ((c/(lam/zp1)) - nujk)/dnu  (:362)
+    rec[1] = ln.nujk / dnu;
+    rec[2] = a * a;
+    rec[3] = K * a * kInvSqrtPi;
+    rec[4] = a;
+    rec[5] = exp(a * a);
+    rec[6] = K;
+    double flag = 0.0;
+    if (!(a <= kYFastMax) || !(a >= 0.0)) flag = 1.0;            // general path (also NaN)
+    else if (K * 1.6e-28 > 1e-18) flag = 2.0;                    // absurd columns: keep exp(-x^2) past |x| = 8
+    rec[7] = flag;
+}
+
+template <bool kZeroPad>
+__global__ __launch_bounds__(kBlock) void mcalf_fused_kernel(const KArgs a) {
+    extern __shared__ __align__(16) double smem[];
+    double* sTabL = smem;                              // 384
+    double* sTabK = sTabL + VT_NINT * VT_LSTRIDE;      // 384
+    double* sCl = sTabK + VT_NINT * VT_LSTRIDE;        // ncl_cap * 8
+    double* sW = sCl + a.ncl_cap * kClStride;          // 2 n_cap + 1
+    double* sRed = sW + (2 * a.n_cap + 1);             // 16
+    double* sF = sRed + 16;                            // tile + 2 n_cap
+    __shared__ double sh_bot;
+
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x / a.ntiles;
+    const int tileIdx = blockIdx.x - s * a.ntiles;
+    const int rowlen = (a.mode == kModeOneComp) ? 5 : a.ndim;
+    const double* p = a.P + (size_t)s * rowlen;
+
+    for (int i = tid; i < 2 * VT_NINT * VT_LSTRIDE; i += kBlock) sTabL[i] = a.tabs[i];
+
+    // ---- 1. decode the parameter vector ---------------------------------------------------
+    double R, cont;
+    int nc, nfill_eff;
+    if (a.mode == kModeOneComp) {                       // hires_fitter.py:379-406
+        R = p[0];
+        cont = p[1];
+        nc = 1;
+        nfill_eff = 0;
+    } else {
+        R = a.freespecres ? p[0] : a.specres_fixed;     // :412-417
+        cont = a.freecont ? (a.freespecres ? p[1] : p[0]) : a.contval_fixed;   // :419-425
+        const double ncv = p[a.startind];
+        // numpy path: int() truncates (:428); JAX path: floor (:616)
+        double nct = kZeroPad ? floor(ncv) : trunc(ncv);
+        nc = (nct >= 1.0) ? ((nct >= (double)a.ncompmax) ? a.ncompmax : (int)nct) : 0;
+        nfill_eff = a.targonly ? 0 : a.nfill;           // :437
+    }
+    const int nl_eff = (a.mode == kModeOneComp && a.onecomp_fill) ? 1 : a.nlines;
+    const int ncl = nc * nl_eff + nfill_eff;
+
+    for (int cl = tid; cl < ncl; cl += kBlock) {
+        double logN, z, b;
+        const LineDev* ln;
+        if (a.mode == kModeOneComp) {
+            logN = p[2]; z = p[3]; b = p[4];
+            ln = a.onecomp_fill ? (a.lines + a.nlines) : (a.lines + cl);
+        } else if (cl < nc * a.nlines) {
+            const int c = cl / a.nlines;
+            const int l = cl - c * a.nlines;
+            const double* q = p + 1 + 3 * c + a.startind;       // :431  (N, z, b)
+            logN = q[0]; z = q[1]; b = q[2];
+            ln = a.lines + l;
+        } else {
+            const int k = cl - nc * a.nlines;
+            const double* q = p + 3 * k + a.endind;             // :439
+            logN = q[0]; z = q[1]; b = q[2];
+            ln = a.lines + a.nlines;
+        }
+        build_line_record(sCl + cl * kClStride, logN, z, b, *ln);
+    }
+
+    // ---- LSF taps --------------------------------------------------------------------------
+    int n;          // half-width in pixels
+    bool bad = false;
+    const double sigma = (R / kFwhmToSigma) / a.velstep;        // :454 / :667
+    if (kZeroPad) {
+        n = a.jax_half;                                         // :549-560 fixed grid
+    } else if (R > a.velstep) {                                 // :445
+        const double nd = ceil(kKernelReach * sigma);           // :458
+        if (!(nd <= (double)a.n_cap)) { bad = true; n = 0; }
+        else n = (int)nd;                                       // x_size = int(2n)+1  (:459)
+    } else {
+        n = 0;
+    }
+    for (int k = tid; k <= 2 * n; k += kBlock) {
+        const double dk = (double)(k - n);
+        double g;
+        if (kZeroPad) g = exp(-(dk * dk) / (2.0 * sigma * sigma));                  // :669
+        else if (n == 0) g = 1.0;
+        else g = exp(-0.5 * dk * dk / (sigma * sigma)) / (sqrt(2.0 * M_PI) * sigma);  // Gaussian1DKernel
+        sW[k] = g;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double ssum = 0.0;
+        for (int k = 0; k <= 2 * n; ++k) ssum += sW[k];
+        double bot = 0.0;
+        for (int k = 0; k <= 2 * n; ++k) {           // normalise (astropy normalize_kernel / :670)
+            const double w = sW[k] / ssum;
+            sW[k] = w;
+            bot += w;
+        }
+        sh_bot = kZeroPad ? 1.0 : bot;               // astropy divides by the tap sum it accumulated
+    }
+    __syncthreads();
+
+    // ---- 2. tau -> flux into the LDS tile ---------------------------------------------------
+    const int t0 = tileIdx * a.tile;
+    const int tlen = min(a.tile, a.npix - t0);
+    const int ext0 = t0 - n;
+    const int extCount = tlen + 2 * n;
+    for (int idx = tid; idx < extCount; idx += kBlock) {
+        int e = ext0 + idx;
+        double fl;
+        if (kZeroPad && (e < 0 || e >= a.npix)) {
+            fl = 0.0;                                  // jnp.convolve 'same' zero padding (:674)
+        } else {
+            if (e < 0 || e >= a.npix) {                // astropy boundary='wrap'
+                e %= a.npix;
+                if (e < 0) e += a.npix;
+            }
+            const double nu = a.nu[e];
+            double tau = 0.0;
+            for (int c = 0; c < ncl; ++c) {
+                const double* rec = sCl + c * kClStride;
+                const double u = fma(nu, rec[0], -rec[1]);
+                const double x2 = u * u;
+                const double flag = rec[7];
+                if (flag == 1.0) {
+                    tau = fma(rec[6], hjert_general(fabs(u), rec[4]), tau);
+                } else if (x2 >= kX2Core) {
+                    tau = fma(rec[3], hjert_wing_scaled(x2, rec[2]), tau);
+                    if (flag == 2.0 && x2 < 745.0) tau = fma(rec[6], exp(-x2), tau);
+                } else {
+                    tau = fma(rec[6], hjert_core(fabs(u), x2, rec[4], rec[2], rec[5], sTabL, sTabK), tau);
+                }
+            }
+            fl = exp(-tau);                            // :377 (product of exp == exp of sum)
+        }
+        sF[idx] = fl;
+    }
+    __syncthreads();
+
+    // ---- 3+4. convolution, continuum, likelihood terms -------------------------------------
+    const double ibot = sh_bot;
+    double acc = 0.0, nnz = 0.0;
+    for (int i = tid; i < tlen; i += kBlock) {
+        const int pix = t0 + i;
+        double top = 0.0;
+        const double* f = sF + i;
+        for (int k = 0; k <= 2 * n; ++k) top = fma(f[k], sW[2 * n - k], top);
+        double m = kZeroPad ? top : top / ibot;
+        if (kZeroPad && (pix < n || pix >= a.npix - n)) m = f[n];     // :677-681 edge reset
+        m *= cont;                                                     // :447 / :683
+        if (bad) m = NAN;
+        if (a.model) a.model[(size_t)s * a.npix + pix] = m;
+        if (a.mode == kModeLogL || a.mode == kModeChi2) {
+            const double d = a.obj[pix] - m;
+            double term = a.ispec2[pix] * (d * d);
+            if (a.mode == kModeLogL) term = (term - a.lgis[pix]) + a.log2pi;  // :294
+            if (!isnan(term)) acc += term;                                     // np.nansum
+            if (m != 0.0) nnz += 1.0;
+        }
+    }
+    if (a.mode == kModeModel || a.mode == kModeOneComp) return;
+
+    acc = wave_sum(acc);
+    nnz = wave_sum(nnz);
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) { sRed[wave] = acc; sRed[4 + wave] = nnz; }
+    __syncthreads();
+    if (tid == 0) {
+        const double ssum = ((sRed[0] + sRed[1]) + sRed[2]) + sRed[3];
+        const double scnt = ((sRed[4] + sRed[5]) + sRed[6]) + sRed[7];
+        if (a.ntiles == 1) {
+            a.out[s] = finalize_value(a.mode, ssum, scnt);
+        } else {
+            a.partial[((size_t)s * a.ntiles + tileIdx) * 2 + 0] = ssum;
+            a.partial[((size_t)s * a.ntiles + tileIdx) * 2 + 1] = scnt;
+        }
+    }
+}
+
+__global__ void mcalf_finalize_kernel(const double* partial, double* out, long batch, int ntiles, int mode) {
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= batch) return;
+    double sum = 0.0, cnt = 0.0;
+    for (int t = 0; t < ntiles; ++t) {
+        sum += partial[(s * ntiles + t) * 2 + 0];
+        cnt += partial[(s * ntiles + t) * 2 + 1];
+    }
+    out[s] = finalize_value(mode, sum, cnt);
+}
+
+__global__ void mcalf_hjert_kernel(const double* x, const double* y, long n, double* out, const double* tabs) {
+    __shared__ double sT[2 * VT_NINT * VT_LSTRIDE];
+    for (int i = threadIdx.x; i < 2 * VT_NINT * VT_LSTRIDE; i += blockDim.x) sT[i] = tabs[i];
+    __syncthreads();
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = hjert(x[i], y[i], sT, sT + VT_NINT * VT_LSTRIDE);
+}
+
+__global__ void mcalf_scale_cube_kernel(const double* lo, const double* hi, const double* cube, long total,
+                                        int ndim, int slot, int int_ncomp, double* theta) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int d = (int)(i % ndim);
+    double v = cube[i] * (hi[d] - lo[d]) + lo[d];    // hires_fitter.py:206 / :214
+    if (int_ncomp && d == slot) v = trunc(v);        // :207-208
+    theta[i] = v;
+}
+
+}  // namespace mcalf
+
+// ==========================================================================================
+// Host side: context + C ABI
+// ==========================================================================================
+using namespace mcalf;
+
+static thread_local std::string g_last_error;
+
+struct mcalf_ctx {
+    int device = 0;
+    std::string arch;
+    std::string err;
+    // problem
+    long npix = 0;
+    int nlines = 0, ncompmax = 0, nfill = 0, freespecres = 0, freecont = 0, conv_mode = 0;
+    int ndim = 0, startind = 0, endind = 0;
+    double specres_fixed = 0, specres_max = 0, contval_fixed = 1, velstep = 0;
+    // geometry
+    int n_cap = 0, tile = 0, ntiles = 0, ncl_cap = 0, jax_half = 0;
+    size_t lds_bytes = 0;
+    // device buffers
+    double *d_nu = nullptr, *d_obj = nullptr, *d_ispec2 = nullptr, *d_lgis = nullptr, *d_tabs = nullptr;
+    LineDev* d_lines = nullptr;
+    // workspaces (grown on demand)
+    double *d_P = nullptr, *d_out = nullptr, *d_partial = nullptr, *d_model = nullptr, *d_bounds = nullptr;
+    size_t cap_P = 0, cap_out = 0, cap_partial = 0, cap_model = 0;
+    hipStream_t stream = nullptr;
+};
+
+static int set_err(mcalf_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return set_err(ctx, MCALF_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+static int pick_device(mcalf_ctx* ctx, int requested, int* out_dev, std::string* arch) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return set_err(ctx, MCALF_ERR_NODEVICE, "no HIP device available (%s); libmcalf_hip has no CPU fallback",
+                       e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    int dev = requested;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= count) return set_err(ctx, MCALF_ERR_INVALID, "device %d out of range (count %d)", dev, count);
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(ctx, MCALF_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only", dev,
+                       prop.gcnArchName);
+    *out_dev = dev;
+    if (arch) *arch = prop.gcnArchName;
+    return MCALF_OK;
+}
+
+template <typename T>
+static int grow(mcalf_ctx* ctx, T** ptr, size_t* cap, size_t need_elems) {
+    if (need_elems <= *cap) return MCALF_OK;
+    if (*ptr) HIP_TRY(ctx, hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)ptr, need_elems * sizeof(T)));
+    *cap = need_elems;
+    return MCALF_OK;
+}
+
+static int upload_tables(mcalf_ctx* ctx, double** d_tabs) {
+    std::vector<double> t(2 * VT_NINT * VT_LSTRIDE);
+    memcpy(t.data(), VT_L_HOST, sizeof(VT_L_HOST));
+    memcpy(t.data() + VT_NINT * VT_LSTRIDE, VT_K1_HOST, sizeof(VT_K1_HOST));
+    HIP_TRY(ctx, hipMalloc((void**)d_tabs, t.size() * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpy(*d_tabs, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    return MCALF_OK;
+}
+
+extern "C" const char* mcalf_version(void) { return "mcalf_hip 0.1 (gfx950, abi 1)"; }
+
+extern "C" const char* mcalf_last_error(const mcalf_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_last_error.c_str();
+}
+
+extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_tabs, ctx->d_lines,
+                    ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
+    if (!sp) return set_err(ctx, MCALF_ERR_INVALID, "spec is NULL");
+    if (sp->npix <= 0 || !sp->wl || !sp->flux || !sp->err)
+        return set_err(ctx, MCALF_ERR_INVALID, "npix must be > 0 and wl/flux/err non-NULL");
+    if (sp->npix > (1 << 30)) return set_err(ctx, MCALF_ERR_RANGE, "npix too large");
+    if (sp->nlines <= 0 || !sp->lines) return set_err(ctx, MCALF_ERR_INVALID, "need at least one line");
+    if (sp->ncompmax < 0 || sp->nfill < 0) return set_err(ctx, MCALF_ERR_INVALID, "negative component counts");
+    if (!(sp->velstep > 0.0)) return set_err(ctx, MCALF_ERR_INVALID, "velstep must be > 0");
+    if (sp->conv_mode != MCALF_CONV_WRAP_NUMPY && sp->conv_mode != MCALF_CONV_SAME_EDGE_JAX)
+        return set_err(ctx, MCALF_ERR_INVALID, "unknown conv_mode %d", sp->conv_mode);
+    double rmax = sp->specres_max;
+    if (!sp->freespecres && !(rmax >= sp->specres_fixed)) rmax = sp->specres_fixed;
+    if (!(rmax > 0.0) || !std::isfinite(rmax))
+        return set_err(ctx, MCALF_ERR_INVALID, "specres_max must be finite and > 0");
+
+    int rc = pick_device(ctx, sp->device, &ctx->device, &ctx->arch);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    ctx->npix = sp->npix;
+    ctx->nlines = sp->nlines;
+    ctx->ncompmax = sp->ncompmax;
+    ctx->nfill = sp->nfill;
+    ctx->freespecres = sp->freespecres ? 1 : 0;
+    ctx->freecont = sp->freecont ? 1 : 0;
+    ctx->conv_mode = sp->conv_mode;
+    ctx->specres_fixed = sp->specres_fixed;
+    ctx->specres_max = rmax;
+    ctx->contval_fixed = sp->contval_fixed;
+    ctx->velstep = sp->velstep;
+    ctx->startind = ctx->freecont + ctx->freespecres;             // hires_fitter.py:169-174
+    ctx->endind = ctx->startind + 3 * ctx->ncompmax + 1;          // :176
+    ctx->ndim = ctx->endind + 3 * ctx->nfill;                     // :184-200
+
+    // LSF reach and tiling
+    const double sigma_max = (rmax / kFwhmToSigma) / sp->velstep;
+    if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX) {
+        ctx->jax_half = (int)std::ceil((float)(kKernelReach * sigma_max));   // :557-559 (float32 ceil)
+        ctx->n_cap = ctx->jax_half;
+    } else {
+        ctx->n_cap = (rmax > sp->velstep) ? (int)std::ceil(kKernelReach * sigma_max) : 0;
+    }
+    ctx->ncl_cap = std::max(1, ctx->ncompmax * ctx->nlines + ctx->nfill);
+    const size_t fixed_doubles = 2 * VT_NINT * VT_LSTRIDE + (size_t)ctx->ncl_cap * kClStride +
+                                 (2 * (size_t)ctx->n_cap + 1) + 16;
+    const size_t max_ext = (kLdsBudget / sizeof(double) > fixed_doubles) ? kLdsBudget / sizeof(double) - fixed_doubles : 0;
+    size_t ext = std::min<size_t>(kExtDefault, max_ext);
+    if (ext < 2 * (size_t)ctx->n_cap + 64)
+        ext = max_ext;   // long kernels: take all the LDS we allow ourselves
+    if (ext < 2 * (size_t)ctx->n_cap + 64)
+        return set_err(ctx, MCALF_ERR_RANGE,
+                       "LSF half-width %d px (specres_max %.3g km/s at %.3g km/s/px) with %d component-lines does not "
+                       "fit the %zu-byte LDS budget", ctx->n_cap, rmax, sp->velstep, ctx->ncl_cap, kLdsBudget);
+    long tile = (long)ext - 2 * ctx->n_cap;
+    if (tile > ctx->npix) tile = ctx->npix;
+    long ntiles = (ctx->npix + tile - 1) / tile;
+    tile = (ctx->npix + ntiles - 1) / ntiles;      // balance
+    ctx->tile = (int)tile;
+    ctx->ntiles = (int)ntiles;
+    ctx->lds_bytes = (fixed_doubles + (size_t)tile + 2 * (size_t)ctx->n_cap) * sizeof(double);
+
+    // spectrum arrays (float64 host arithmetic identical to the reference's numpy expressions)
+    std::vector<double> nu(ctx->npix), is2(ctx->npix), lg(ctx->npix);
+    for (long i = 0; i < ctx->npix; ++i) {
+        const double wave_cm = sp->wl[i] / 1e8;            // :376
+        nu[i] = kCcgs / wave_cm;                           // :362 at zp1 = 1
+        is2[i] = 1.0 / (sp->err[i] * sp->err[i]);          // :292
+        lg[i] = std::log(is2[i]);                          // :294
+    }
+    std::vector<LineDev> lines(ctx->nlines + 1);
+    for (int l = 0; l <= ctx->nlines; ++l) {
+        const mcalf_line& src = (l < ctx->nlines) ? sp->lines[l] : sp->fill;
+        lines[l].wrest_cm = src.wrest_A / 1e8;             // :376
+        lines[l].f = src.f;
+        lines[l].gamma = src.gamma;
+        lines[l].nujk = kCcgs / lines[l].wrest_cm;         // :359
+    }
+    const size_t nb = (size_t)ctx->npix * sizeof(double);
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_nu, nb));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_obj, nb));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ispec2, nb));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_lgis, nb));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_lines, lines.size() * sizeof(LineDev)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_nu, nu.data(), nb, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_obj, sp->flux, nb, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_ispec2, is2.data(), nb, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_lgis, lg.data(), nb, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_lines, lines.data(), lines.size() * sizeof(LineDev), hipMemcpyHostToDevice));
+    rc = upload_tables(ctx, &ctx->d_tabs);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_create(const mcalf_spec* spec, mcalf_ctx** out) {
+    if (!out) return set_err(nullptr, MCALF_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    mcalf_ctx* ctx = new (std::nothrow) mcalf_ctx();
+    if (!ctx) return set_err(nullptr, MCALF_ERR_NOMEM, "out of host memory");
+    int rc = create_impl(spec, ctx);
+    if (rc != MCALF_OK) {
+        g_last_error = ctx->err;
+        mcalf_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_info(const mcalf_ctx* ctx, mcalf_info_t* info) {
+    if (!ctx || !info) return set_err(nullptr, MCALF_ERR_INVALID, "NULL argument");
+    memset(info, 0, sizeof *info);
+    info->abi_version = MCALF_ABI_VERSION;
+    info->ndim = ctx->ndim;
+    info->startind = ctx->startind;
+    info->endind = ctx->endind;
+    info->n_cap = ctx->n_cap;
+    info->tile = ctx->tile;
+    info->ntiles = ctx->ntiles;
+    info->device = ctx->device;
+    info->npix = ctx->npix;
+    snprintf(info->arch, sizeof info->arch, "%s", ctx->arch.c_str());
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_reserve(mcalf_ctx* ctx, int64_t batch) {
+    if (!ctx || batch < 0) return set_err(ctx, MCALF_ERR_INVALID, "bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, (size_t)batch * std::max(ctx->ndim, 5)))) return rc;
+    if ((rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
+    if ((rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 2))) return rc;
+    return MCALF_OK;
+}
+
+// Enqueue the fused kernel (+ finalize when tiled) on `stream`.
+static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill,
+                  double* d_out, double* d_model, hipStream_t stream) {
+    if (batch == 0) return MCALF_OK;
+    if (batch < 0 || batch * (int64_t)ctx->ntiles > 0x7fffffffLL)
+        return set_err(ctx, MCALF_ERR_RANGE, "batch %lld too large", (long long)batch);
+    const bool reduces = (mode == kModeLogL || mode == kModeChi2);
+    if (reduces && ctx->ntiles > 1) {
+        int rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 2);
+        if (rc) return rc;
+    }
+    KArgs a;
+    a.nu = ctx->d_nu; a.obj = ctx->d_obj; a.ispec2 = ctx->d_ispec2; a.lgis = ctx->d_lgis;
+    a.P = dP; a.partial = ctx->d_partial; a.out = d_out; a.model = d_model;
+    a.lines = ctx->d_lines; a.tabs = ctx->d_tabs;
+    a.npix = (int)ctx->npix; a.ndim = ctx->ndim; a.ntiles = ctx->ntiles; a.tile = ctx->tile;
+    a.n_cap = ctx->n_cap; a.ncl_cap = ctx->ncl_cap;
+    a.nlines = ctx->nlines; a.ncompmax = ctx->ncompmax; a.nfill = ctx->nfill;
+    a.startind = ctx->startind; a.endind = ctx->endind;
+    a.freespecres = ctx->freespecres; a.freecont = ctx->freecont; a.conv_mode = ctx->conv_mode;
+    a.targonly = targonly; a.mode = mode; a.jax_half = ctx->jax_half; a.onecomp_fill = onecomp_fill;
+    a.specres_fixed = ctx->specres_fixed; a.contval_fixed = ctx->contval_fixed; a.velstep = ctx->velstep;
+    a.log2pi = std::log(2.0 * M_PI);
+    const dim3 grid((unsigned)(batch * ctx->ntiles)), block(kBlock);
+    if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX)
+        hipLaunchKernelGGL(mcalf_fused_kernel<true>, grid, block, ctx->lds_bytes, stream, a);
+    else
+        hipLaunchKernelGGL(mcalf_fused_kernel<false>, grid, block, ctx->lds_bytes, stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    if (reduces && ctx->ntiles > 1) {
+        const int fb = 256;
+        hipLaunchKernelGGL(mcalf_finalize_kernel, dim3((unsigned)((batch + fb - 1) / fb)), dim3(fb), 0, stream,
+                           ctx->d_partial, d_out, (long)batch, ctx->ntiles, mode);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_loglike_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, double* dlogL,
+                                          void* stream) {
+    if (!ctx || (batch > 0 && (!dP || !dlogL))) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch(ctx, kModeLogL, dP, batch, 0, 0, dlogL, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int mcalf_model_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, int32_t targonly,
+                                        double* dflux, void* stream) {
+    if (!ctx || (batch > 0 && (!dP || !dflux))) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch(ctx, kModeModel, dP, batch, targonly ? 1 : 0, 0, nullptr, dflux, (hipStream_t)stream);
+}
+
+// Host-pointer entries: stage through the context's workspaces on its private stream.
+static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
+                    double* out_scalar, double* out_model) {
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    if (batch < 0) return set_err(ctx, MCALF_ERR_INVALID, "negative batch");
+    if (batch == 0) return MCALF_OK;
+    if (!P || (!out_scalar && !out_model)) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, (size_t)batch * rowlen))) return rc;
+    if (out_scalar && (rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
+    if (out_model && (rc = grow(ctx, &ctx->d_model, &ctx->cap_model, (size_t)batch * ctx->npix))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_P, P, (size_t)batch * rowlen * sizeof(double), hipMemcpyHostToDevice,
+                                ctx->stream));
+    rc = launch(ctx, mode, ctx->d_P, batch, targonly, fill, out_scalar ? ctx->d_out : nullptr,
+                out_model ? ctx->d_model : nullptr, ctx->stream);
+    if (rc) return rc;
+    if (out_scalar)
+        HIP_TRY(ctx, hipMemcpyAsync(out_scalar, ctx->d_out, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    if (out_model)
+        HIP_TRY(ctx, hipMemcpyAsync(out_model, ctx->d_model, (size_t)batch * ctx->npix * sizeof(double),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_loglike_batch(mcalf_ctx* ctx, const double* P, int64_t batch, double* logL) {
+    return run_host(ctx, kModeLogL, P, batch, ctx ? ctx->ndim : 0, 0, 0, logL, nullptr);
+}
+
+extern "C" int mcalf_chi2_batch(mcalf_ctx* ctx, const double* P, int64_t batch, double* chi2) {
+    return run_host(ctx, kModeChi2, P, batch, ctx ? ctx->ndim : 0, 0, 0, chi2, nullptr);
+}
+
+extern "C" int mcalf_model_batch(mcalf_ctx* ctx, const double* P, int64_t batch, int32_t targonly, double* flux) {
+    return run_host(ctx, kModeModel, P, batch, ctx ? ctx->ndim : 0, targonly ? 1 : 0, 0, nullptr, flux);
+}
+
+extern "C" int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batch, int32_t fill, double* flux) {
+    return run_host(ctx, kModeOneComp, Q, batch, 5, 0, fill ? 1 : 0, nullptr, flux);
+}
+
+extern "C" int mcalf_scale_cube_batch(mcalf_ctx* ctx, const double* lo, const double* hi, const double* cube,
+                                      int64_t batch, int32_t int_ncomp, double* theta) {
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    if (batch < 0) return set_err(ctx, MCALF_ERR_INVALID, "negative batch");
+    if (batch == 0) return MCALF_OK;
+    if (!lo || !hi || !cube || !theta) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t total = (size_t)batch * ctx->ndim;
+    int rc;
+    if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, total))) return rc;
+    if ((rc = grow(ctx, &ctx->d_model, &ctx->cap_model, total))) return rc;
+    if (!ctx->d_bounds) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bounds, 2 * (size_t)ctx->ndim * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bounds, lo, ctx->ndim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bounds + ctx->ndim, hi, ctx->ndim * sizeof(double), hipMemcpyHostToDevice,
+                                ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_P, cube, total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(mcalf_scale_cube_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       ctx->d_bounds, ctx->d_bounds + ctx->ndim, ctx->d_P, (long)total, ctx->ndim, ctx->startind,
+                       int_ncomp, ctx->d_model);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(theta, ctx->d_model, total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_voigt_hjerting(const double* x, const double* y, int64_t n, double* out, int32_t device) {
+    if (n < 0 || (n > 0 && (!x || !y || !out))) return set_err(nullptr, MCALF_ERR_INVALID, "bad arguments");
+    if (n == 0) return MCALF_OK;
+    int dev = 0;
+    int rc = pick_device(nullptr, device, &dev, nullptr);
+    if (rc) return rc;
+    HIP_TRY(nullptr, hipSetDevice(dev));
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr, *dtabs = nullptr;
+    const size_t nb = (size_t)n * sizeof(double);
+    HIP_TRY(nullptr, hipMalloc((void**)&dx, nb));
+    HIP_TRY(nullptr, hipMalloc((void**)&dy, nb));
+    HIP_TRY(nullptr, hipMalloc((void**)&dout, nb));
+    rc = upload_tables(nullptr, &dtabs);
+    if (rc == MCALF_OK) {
+        hipError_t e = hipMemcpy(dx, x, nb, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dy, y, nb, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(mcalf_hjert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dx, dy, (long)n,
+                               dout, dtabs);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(out, dout, nb, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = set_err(nullptr, MCALF_ERR_HIP, "hjerting: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    if (dtabs) (void)hipFree(dtabs);
+    return rc;
+}

@@ -1,0 +1,359 @@
+"""Host-side mirror of `mcalf.routines.hires_fitter.als_fitter` for the likelihood hot path.
+
+Same class name, constructor keywords, method names, argument order and return
+conventions as the reference (hires_fitter.py:30-518), so an existing solver driver can
+switch `from mcalf.routines import hires_fitter` to this module unchanged.  Every
+likelihood / model method is a batch-of-one call into the HIP library
+(`libmcalf_hip.so`); `loglike_batch` / `model_batch` are the vectorised entries.
+
+What is NOT here (out of scope): INI parsing, solver dispatch,
+plotting, chain readers.  linetools is replaced by an explicit `linepars=` argument
+plus a tiny built-in table (`LINE_TABLE`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import gc
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .. import _lib
+
+# (wrest [A], f, gamma [1/s]).  CIV: pinned by the reference's own test spectra
+# (SURVEY.md section 4).  HI 1215: Morton (2003), NOT pinned (linetools absent).
+LINE_TABLE = {
+    "CIV 1548": (1548.204, 0.1899, 2.643e8),
+    "CIV 1550": (1550.781, 0.09475, 2.628e8),
+    "HI 1215": (1215.67, 0.4164, 6.265e8),
+}
+
+
+def sigma_clipped_median(x, sigma=3.0, maxiters=5):
+    """Median after iterative sigma clipping about the median (the `med` that
+    `astropy.stats.sigma_clipped_stats` returns with its defaults; hires_fitter.py:85).
+    Pinned only for grids where nothing is clipped (both reference fixtures)."""
+    x = np.asarray(x, dtype=float)
+    x = x[np.isfinite(x)]
+    for _ in range(maxiters):
+        med, std = np.median(x), np.std(x)
+        keep = np.abs(x - med) <= sigma * std
+        if keep.all():
+            break
+        x = x[keep]
+    return float(np.median(x))
+
+
+def _read_ascii_table(path, coldef):
+    """Minimal stand-in for `astropy.io.ascii.read` (hires_fitter.py:69-72) on whitespace
+    tables whose column names are either a `# Wave Flux Err` comment line (np.savetxt
+    header, as in the reference's testdata) or a bare first line."""
+    names, skip = None, 0
+    with open(path) as fh:
+        for line in fh:
+            s = line.strip()
+            if not s:
+                skip += 1
+                continue
+            if s.startswith("#"):
+                names = s.lstrip("#").split()
+                skip += 1
+                continue
+            try:
+                [float(t) for t in s.split()]
+            except ValueError:
+                names = s.split()
+                skip += 1
+            break
+    data = np.loadtxt(path, comments="#", skiprows=skip, ndmin=2)
+    if names is None or len(names) != data.shape[1]:
+        names = list(coldef)
+    idx = [names.index(c) for c in coldef]
+    return data[:, idx[0]], data[:, idx[1]], data[:, idx[2]]
+
+
+class als_fitter:
+    """Drop-in for `mcalf.routines.hires_fitter.als_fitter` (hires_fitter.py:30).
+
+    Extra keywords (all optional): `spectrum=(wl, flux, err)` arrays instead of a file;
+    `linepars=[(wrest, f, gamma), ...]` instead of a linetools lookup; `velstep=`;
+    `conv_mode='numpy'|'jax'`; `device=` HIP ordinal.
+    """
+
+    def __init__(self, specfile, fitrange, fitlines, ncomp, nfill=0, specres=[7.0], contval=[1.0],
+                 Nrange=[11.5, 16], brange=[1, 30], zrange=None, Nrangefill=[11.5, 16], brangefill=[1, 30],
+                 wrangefill=None, coldef=['Wave', 'Flux', 'Err'], Gpriors=None, Asymmlike=False, debug=False,
+                 *, spectrum=None, linepars=None, velstep=None, conv_mode="numpy", device=-1):
+        self.debug = debug
+        self.specfile = specfile
+        self.fitrange = fitrange
+        self.fitlines = fitlines
+        self.Gpriors = Gpriors
+        self.Asymmlike = Asymmlike
+        if self.Asymmlike:
+            raise NotImplementedError("Asymmlike veto is a 'next' row (SURVEY.md section 8f); not built yet")
+        self.specres = list(np.atleast_1d(specres))
+        self.contval = list(np.atleast_1d(contval))
+        self.ncompmin = ncomp[0]
+        self.ncompmax = ncomp[1]
+        self.nfill = nfill
+        self.freecont = len(self.contval) > 1          # hires_fitter.py:54-57
+        self.freespecres = len(self.specres) > 1       # :59-62
+        self.clight = 2.9979245e5                      # :65
+        self.ccgs = 2.9979245e10                       # :66
+
+        if spectrum is not None:
+            obj_wl, obj, obj_noise = (np.asarray(a, dtype=float) for a in spectrum)
+        else:
+            obj_wl, obj, obj_noise = _read_ascii_table(specfile, coldef)
+        okrange = np.zeros_like(obj_wl, dtype=bool)    # :75-78
+        self.numfitranges = len(self.fitrange)
+        for lo, hi in self.fitrange:
+            okrange[(obj_wl > lo) & (obj_wl < hi)] = True
+        self.obj = np.ascontiguousarray(obj[okrange])
+        self.obj_noise = np.ascontiguousarray(obj_noise[okrange])
+        self.obj_wl = np.ascontiguousarray(obj_wl[okrange])
+
+        if velstep is None:                            # :84-87
+            velsteps = (self.obj_wl[1:] - self.obj_wl[:-1]) / self.obj_wl[1:] * self.clight
+            velstep = sigma_clipped_median(velsteps)
+        self.velstep = float(velstep)
+
+        self.numlines = len(fitlines)                  # :93-116
+        if linepars is None:
+            try:
+                linepars = [LINE_TABLE[name] for name in fitlines]
+            except KeyError as exc:
+                raise KeyError(f"line {exc} is not in the built-in table; pass linepars=[(wrest,f,gamma),...]")
+        self.linepars = [dict(wrest=float(w), f=float(f), gamma=float(g)) for (w, f, g) in linepars]
+        self.linefill = dict(self.linepars[0])         # :120-121
+        self.linefill["wrest"] = 250.0
+
+        # prior box, in the reference's order [R?][cont?][ncomp][N,z,b]*ncompmax [N,z,b]*nfill
+        # (hires_fitter.py:124-200)
+        self.cont_lims, self.res_lims = np.array(self.contval), np.array(self.specres)
+        self.N_lims, self.b_lims = np.array(Nrange), np.array(brange)
+        self.N_lims_fill, self.b_lims_fill = np.array(Nrangefill), np.array(brangefill)
+        w0 = self.linepars[0]["wrest"]
+        wf = self.linefill["wrest"]
+        self.z_lims = [self._zbox(zrange, k, self.ncompmax, w0, as_wave=False,
+                                  default=(self.fitrange[0][0] + 0.25, self.fitrange[0][1] - 0.25),
+                                  what="Zrange") for k in range(self.ncompmax)]
+        self.z_lims_fill = [self._zbox(wrangefill, k, self.nfill, wf, as_wave=True,
+                                       default=(np.min(self.obj_wl) + 0.25, np.max(self.obj_wl) - 0.25),
+                                       what="Wrangefill") for k in range(self.nfill)]
+        self.startind = int(self.freecont) + int(self.freespecres)     # :169-174
+        self.endind = self.startind + 3 * self.ncompmax + 1            # :176
+        head = ([self.res_lims] if self.freespecres else []) + ([self.cont_lims] if self.freecont else [])
+        comps = [lim for k in range(self.ncompmax) for lim in (self.N_lims, self.z_lims[k], self.b_lims)]
+        fills = [lim for k in range(self.nfill) for lim in (self.N_lims_fill, self.z_lims_fill[k], self.b_lims_fill)]
+        self.bounds = head + [ncomp] + comps + fills
+        self.ndim = len(self.bounds)
+        self._lo = np.array([np.min(b) for b in self.bounds], dtype=float)
+        self._hi = np.array([np.max(b) for b in self.bounds], dtype=float)
+
+        self.conv_mode = conv_mode
+        self._ctx = None
+        self._open_context(device)
+
+    @staticmethod
+    def _zbox(spec, k, count, wrest, as_wave, default, what):
+        """Redshift box of slot k.  `spec` None -> from the wavelength window `default`
+        (hires_fitter.py:138-139,155-156); 2 numbers -> shared box; 2*count numbers -> per slot.
+        `as_wave`: numbers are observed wavelengths (fillers, :158-162) rather than redshifts."""
+        if spec is None:
+            lo, hi, as_wave = default[0], default[1], True
+        elif len(spec) == 2:
+            lo, hi = spec[0], spec[1]
+        elif (as_wave and len(spec) == 2 * count) or (not as_wave and len(spec) >= 2 * count):
+            lo, hi = spec[2 * k], spec[2 * k + 1]
+        else:
+            raise ValueError(f"{what} keyword not understood.")
+        if as_wave:
+            lo, hi = lo / wrest - 1., hi / wrest - 1.
+        return np.array((lo, hi))
+
+    # ------------------------------------------------------------------ device context
+    def _open_context(self, device):
+        lib = _lib.load()
+        sp = _lib.mcalf_spec()
+        sp.npix = self.obj_wl.size
+        self._keep = (np.ascontiguousarray(self.obj_wl), np.ascontiguousarray(self.obj),
+                      np.ascontiguousarray(self.obj_noise))
+        pd = C.POINTER(C.c_double)
+        sp.wl, sp.flux, sp.err = (a.ctypes.data_as(pd) for a in self._keep)
+        sp.velstep = self.velstep
+        sp.nlines = self.numlines
+        lines = (_lib.mcalf_line * self.numlines)()
+        for i, lp in enumerate(self.linepars):
+            lines[i] = _lib.mcalf_line(lp["wrest"], lp["f"], lp["gamma"])
+        sp.lines = lines
+        sp.fill = _lib.mcalf_line(self.linefill["wrest"], self.linefill["f"], self.linefill["gamma"])
+        sp.ncompmax = int(self.ncompmax)
+        sp.nfill = int(self.nfill)
+        sp.freespecres = int(self.freespecres)
+        sp.freecont = int(self.freecont)
+        jax = (self.conv_mode == "jax")
+        # numpy path: float(max(specres)) (:415-417); JAX path: specres[0] (:572)
+        sp.specres_fixed = float(self.specres[0]) if jax else float(max(self.specres))
+        sp.specres_max = float(max(self.specres))
+        sp.contval_fixed = float(self.contval[0])
+        sp.conv_mode = _lib.MCALF_CONV_SAME_EDGE_JAX if jax else _lib.MCALF_CONV_WRAP_NUMPY
+        sp.device = int(device)
+        ctx = C.c_void_p()
+        _lib.check(lib.mcalf_create(C.byref(sp), C.byref(ctx)))
+        self._ctx = ctx
+        self._lib = lib
+        info = _lib.mcalf_info_t()
+        _lib.check(lib.mcalf_info(ctx, C.byref(info)), ctx)
+        assert info.ndim == self.ndim and info.startind == self.startind and info.endind == self.endind
+        self.info = info
+
+    def close(self):
+        if self._ctx is not None:
+            self._lib.mcalf_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, type, value, trace):
+        self.close()
+        gc.collect()
+
+    # ------------------------------------------------------------------ prior transforms
+    def _scale_cube_pc(self, cube):
+        """hires_fitter.py:202-209."""
+        cube2 = np.copy(cube)
+        for ii in range(len(cube)):
+            cube2[ii] = cube2[ii] * np.ptp(self.bounds[ii]) + np.min(self.bounds[ii])
+            if ii == self.startind:
+                cube2[ii] = int(cube2[ii])
+        return cube2
+
+    def _scale_cube_mn(self, cube, ndim, nparam):
+        """hires_fitter.py:211-216 (in place)."""
+        for ii in range(ndim):
+            cube[ii] = cube[ii] * np.ptp(self.bounds[ii]) + np.min(self.bounds[ii])
+        return cube
+
+    def scale_cube_batch(self, cubes, int_ncomp=True):
+        """Vectorised prior transform on the device (rows of `cubes` in [0,1]^ndim)."""
+        cubes = np.ascontiguousarray(cubes, dtype=float).reshape(-1, self.ndim)
+        out = np.empty_like(cubes)
+        pd = C.POINTER(C.c_double)
+        _lib.check(self._lib.mcalf_scale_cube_batch(
+            self._ctx, self._lo.ctypes.data_as(pd), self._hi.ctypes.data_as(pd), cubes.ctypes.data_as(pd),
+            cubes.shape[0], int(bool(int_ncomp)), out.ctypes.data_as(pd)), self._ctx)
+        return out
+
+    def lnprior(self, p):
+        """hires_fitter.py:218-234."""
+        ndim = len(p)
+        if all(b[0] <= v <= b[1] for v, b in zip(p, self.bounds)):
+            pav = 0
+            if self.Gpriors is not None:
+                for par in range(ndim):
+                    if self.Gpriors[2 * par] != 'none' and self.Gpriors[(2 * par) + 1] != 'none':
+                        val = float(self.Gpriors[2 * par])
+                        sig = float(self.Gpriors[(2 * par) + 1])
+                        pav += -0.5 * (((p[par] - val) / sig) ** 2 + np.log(2. * np.pi * sig ** 2))
+            return pav
+        return -np.inf
+
+    # ------------------------------------------------------------------ batched entries
+    def _rows(self, P, width):
+        P = np.ascontiguousarray(P, dtype=float)
+        if P.ndim == 1:
+            P = P.reshape(1, -1)
+        if P.shape[1] != width:
+            raise ValueError(f"parameter rows must have {width} entries, got {P.shape[1]}")
+        return P
+
+    def loglike_batch(self, P):
+        """logL[i] = lnlhood_worker(P[i]) for every row."""
+        P = self._rows(P, self.ndim)
+        out = np.empty(P.shape[0])
+        pd = C.POINTER(C.c_double)
+        _lib.check(self._lib.mcalf_loglike_batch(self._ctx, P.ctypes.data_as(pd), P.shape[0],
+                                                 out.ctypes.data_as(pd)), self._ctx)
+        return out
+
+    def chi2_batch(self, P):
+        P = self._rows(P, self.ndim)
+        out = np.empty(P.shape[0])
+        pd = C.POINTER(C.c_double)
+        _lib.check(self._lib.mcalf_chi2_batch(self._ctx, P.ctypes.data_as(pd), P.shape[0],
+                                              out.ctypes.data_as(pd)), self._ctx)
+        return out
+
+    def model_batch(self, P, targonly=False):
+        """model[i, :] = reconstruct_spec(P[i], targonly)."""
+        P = self._rows(P, self.ndim)
+        out = np.empty((P.shape[0], self.obj_wl.size))
+        pd = C.POINTER(C.c_double)
+        _lib.check(self._lib.mcalf_model_batch(self._ctx, P.ctypes.data_as(pd), P.shape[0], int(bool(targonly)),
+                                               out.ctypes.data_as(pd)), self._ctx)
+        return out
+
+    def onecomp_batch(self, Q, fill=False):
+        Q = self._rows(Q, 5)
+        out = np.empty((Q.shape[0], self.obj_wl.size))
+        pd = C.POINTER(C.c_double)
+        _lib.check(self._lib.mcalf_onecomp_batch(self._ctx, Q.ctypes.data_as(pd), Q.shape[0], int(bool(fill)),
+                                                 out.ctypes.data_as(pd)), self._ctx)
+        return out
+
+    # ------------------------------------------------------------------ reference callables
+    def chi2(self, p):
+        """hires_fitter.py:236-248 (returns `(+inf, [])` for an all-zero model, else a float)."""
+        v = float(self.chi2_batch(p)[0])
+        if v == np.inf:
+            return +np.inf, []
+        return v
+
+    def lnlhood_pc(self, p):
+        """hires_fitter.py:250-262 -> (logL, [])."""
+        return self.lnlhood_worker(p), []
+
+    def lnlhood_dy(self, p):
+        """hires_fitter.py:264-272 -> float."""
+        return self.lnlhood_worker(p)
+
+    def lnlhood_mn(self, p, ndim, nparam):
+        """hires_fitter.py:274-285: `p` may be a C double pointer, hence the copy."""
+        parr = np.array([p[x] for x in range(self.ndim)])
+        return self.lnlhood_worker(parr)
+
+    def lnlhood_worker(self, p):
+        """hires_fitter.py:287-328."""
+        return float(self.loglike_batch(p)[0])
+
+    def reconstruct_spec(self, p, targonly=False):
+        """hires_fitter.py:409-449."""
+        return self.model_batch(p, targonly)[0]
+
+    def reconstruct_onecomp(self, specresolution, continuum, N, z, b):
+        """hires_fitter.py:379-392."""
+        return self.onecomp_batch([specresolution, _scalar(continuum), N, z, b], fill=False)[0]
+
+    def reconstruct_onecomp_fill(self, specresolution, continuum, N, z, b):
+        """hires_fitter.py:394-406."""
+        return self.onecomp_batch([specresolution, _scalar(continuum), N, z, b], fill=True)[0]
+
+    def get_jax_likelihood(self):
+        """hires_fitter.py:521-695 returns a JAX-traceable closure.  JAX is not a dependency
+        of this package (and the north-star excludes JAX dispatch); use `conv_mode='jax'`
+        with `loglike_batch` for that path's semantics evaluated by the HIP kernel."""
+        raise ImportError("JAX is not available; construct als_fitter(..., conv_mode='jax') and call "
+                          "loglike_batch / lnlhood_dy instead")
+
+
+def _scalar(v):
+    return float(np.asarray(v, dtype=float).reshape(-1)[0])

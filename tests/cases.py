@@ -1,0 +1,25 @@
+"""Shared helpers for the parity tests: build the oracle Problem that corresponds to a set
+of als_fitter kwargs, and synthesise config spectra with the oracle."""
+import numpy as np
+
+from oracle import numpy_oracle as oracle
+
+
+def problem_from_kwargs(kw):
+    wl, flux, err = kw["spectrum"]
+    return oracle.Problem(
+        wl, flux, err, kw["linepars"], tuple(kw["ncomp"]), nfill=kw.get("nfill", 0),
+        specres=kw.get("specres", [7.0]), contval=kw.get("contval", [1.0]),
+        Nrange=kw.get("Nrange", [11.5, 16]), brange=kw.get("brange", [1, 30]), zrange=kw.get("zrange"),
+        Nrangefill=kw.get("Nrangefill", [11.5, 16]), brangefill=kw.get("brangefill", [1, 30]),
+        fitrange=kw.get("fitrange"))
+
+
+def oracle_synth(kw, p):
+    return oracle.reconstruct_spec(problem_from_kwargs(kw), p)
+
+
+def seeded_noise():
+    """The noise realisation of testdata/generate_from_model.py:52-54."""
+    np.random.seed(42)
+    return np.random.normal(0, 0.02, size=1998)
