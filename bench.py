@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the MC-ALF likelihood hot path on MI355X.
+
+A "step" is one `loglike_batch` pass over one batch of synthetic live points (BASELINE.json
+config B at N=1: batch=1024, ncomp=8, CIV doublet, npix=4000, fixed 8 km/s LSF) with the
+parameter matrix already resident in HBM and logL left in HBM.  With N GPUs every rank
+runs the same per-GPU batch (weak scaling; config B -> 8 x B, the C -> D pattern of
+BASELINE.json) and the per-sample logL shards are gathered to rank 0 over RCCL each step.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import mcalf_amd  # noqa: E402
+from mcalf_amd import _lib, workloads  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 peak
+
+
+def hip_synth(kw, p):
+    """Synthesise a truth spectrum with the HIP path itself (no oracle in the product path)."""
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        return fit.reconstruct_spec(np.asarray(p, dtype=float))
+
+
+def cpu_baseline(kw, P, budget_s):
+    """Time the numpy/scipy oracle (the closest runnable stand-in for the reference's numpy
+    path) on a bounded sample of the same workload.  Checker/baseline only."""
+    from oracle import numpy_oracle as oracle
+    wl, flux, err = kw["spectrum"]
+    prob = oracle.Problem(wl, flux, err, kw["linepars"], tuple(kw["ncomp"]), nfill=kw.get("nfill", 0),
+                          specres=kw["specres"], Nrange=kw["Nrange"], brange=kw["brange"], zrange=kw["zrange"],
+                          Nrangefill=kw.get("Nrangefill", [11.5, 16]), brangefill=kw.get("brangefill", [1, 30]),
+                          fitrange=kw["fitrange"])
+    oracle.lnlhood_worker(prob, P[0])          # warm
+    vals, t0 = [], time.perf_counter()
+    for row in P:
+        vals.append(oracle.lnlhood_worker(prob, row))
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return np.array(vals), dt, prob
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="B", choices=["A", "B", "C", "E"])
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    kw, batch, seed = workloads.config(args.config, hip_synth)
+    if args.batch:
+        batch = args.batch
+    # every rank draws the job-wide matrix from one seed and keeps its contiguous row block
+    P_all = workloads.draw_P(kw, batch * world, np.random.default_rng(seed), damped=2 if args.config == "E" else 0)
+    P_host = np.ascontiguousarray(P_all[rank * batch:(rank + 1) * batch])
+    fit = mcalf_amd.als_fitter(None, device=local_rank, **kw)
+    npix, ndim, nlines = fit.obj_wl.size, fit.ndim, fit.numlines
+    nc = P_host[:, fit.startind].astype(int)
+    comp_pix = float(nc.sum()) * npix                       # component x pixel evals per step (this rank)
+    line_pix = float((nc * nlines + fit.nfill).sum()) * npix
+
+    dP = torch.from_numpy(P_host).to(dev)
+    dlogL = torch.empty(batch, dtype=torch.float64, device=dev)
+    gathered = [torch.empty(batch, dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
+    _lib.check(fit._lib.mcalf_reserve(fit._ctx, batch), fit._ctx)
+    stream = torch.cuda.current_stream()
+    st = C.c_void_p(stream.cuda_stream)
+    launch = fit._lib.mcalf_loglike_batch_device
+    ctx, pP, pL = fit._ctx, dP.data_ptr(), dlogL.data_ptr()
+
+    def step():
+        rc = launch(ctx, pP, batch, pL, st)
+        if rc:
+            _lib.check(rc, ctx)
+        if world > 1:
+            dist.gather(dlogL, gathered, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([comp_pix, line_pix], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    comp_pix_job, line_pix_job = (float(v) for v in tot.tolist())
+
+    # dominant kernel: average launch duration from HIP events on the launch stream (N=1: the
+    # stream carries nothing but the fused kernel; N>1: the gather is on RCCL's own stream)
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
+    logL_dev = dlogL.cpu().numpy()
+
+    out = None
+    if rank == 0:
+        n_half = fit.info.n_cap
+        alg_bytes = (8 * ndim + 8) * batch + 24 * npix
+        alg_flops = 40.0 * line_pix + (31 + 4 * n_half) * npix * batch
+        ach_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "component-pixel Voigt evals/s (sum_s ncomp_s * npix / t), logL batch on MI355X",
+            "value": comp_pix_job * args.steps / elapsed,
+            "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config {args.config}: CIV 1548/1550 synthetic spectrum" if args.config != "E"
+                       else "BASELINE config E: HI 1215 damped", "batch_per_gpu": batch, "global_batch": batch * world,
+                       "npix": npix, "ncomp": list(kw["ncomp"]), "nlines": nlines, "nfill": fit.nfill, "ndim": ndim,
+                       "specres": list(kw["specres"]), "lsf_taps": 2 * n_half + 1, "tiles_per_sample": fit.info.ntiles,
+                       "parallelism": f"dp{world} rows sharded, RCCL gather of logL to rank 0" if world > 1 else "single GPU"},
+            "logL_per_s": batch * world * args.steps / elapsed,
+            "line_pixel_evals_per_s": line_pix_job * args.steps / elapsed,
+            "kernel_ms": kern_ms,
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "mcalf_fused_kernel", "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "fused path is FP64-VALU bound, not HBM bound (SURVEY.md 8d); see roofline_valu"},
+            "roofline_valu": {"bound": "fp64_valu", "achieved": alg_flops / (kern_ms * 1e-3) / 1e12,
+                              "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": alg_flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                              "algorithmic_flops_per_launch": alg_flops},
+        }
+        if args.cpu_seconds > 0:
+            vals, dt, _ = cpu_baseline(kw, P_host, args.cpu_seconds)
+            k = len(vals)
+            out["cpu_baseline"] = {
+                "value": float(nc[:k].sum()) * npix / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+                "sample": f"first {k} of {batch} rows of the same parameter matrix, numpy/scipy float64 oracle "
+                          f"(oracle/numpy_oracle.py), {dt:.1f} s, {dt / k * 1e3:.2f} ms per logL",
+                "host_cpus": os.cpu_count()}
+            out["parity"] = {"max_abs_dlogL_vs_oracle": float(np.abs(vals - logL_dev[:k]).max()), "rows": k}
+    fit.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

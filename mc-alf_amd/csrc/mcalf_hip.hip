@@ -291,7 +291,14 @@ __global__ void mcalf_scale_cube_kernel(const double* lo, const double* hi, cons
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int d = (int)(i % ndim);
-    double v = cube[i] * (hi[d] - lo[d]) + lo[d];    // hires_fitter.py:206 / :214
+    // separately rounded multiply and add (no FMA contraction), as numpy evaluates
+    // cube*ptp + min (hires_fitter.py:206 / :214)
+    double v;
+    {
+#pragma clang fp contract(off)
+        const double scaled = cube[i] * (hi[d] - lo[d]);
+        v = scaled + lo[d];
+    }
     if (int_ncomp && d == slot) v = trunc(v);        // :207-208
     theta[i] = v;
 }

@@ -55,8 +55,8 @@ def test_golden_G1_G2_models_from_the_device():
         P = np.array([[1.0, workloads.TRUTH_N[i], workloads.TRUTH_Z[i], workloads.TRUTH_B[i]] for i in range(10)])
         parts = fit.model_batch(P)
         one = fit.reconstruct_onecomp(8.0, [1.0], 13.8, 3.0, 15.0)
-    assert np.abs(d1[:, 1] - noise - m1).max() < 1e-12
-    assert np.abs(d2[:, 1] - noise - np.prod(parts, axis=0)).max() < 1e-12
+    assert np.abs(d1[:, 1] - noise - m1).max() < 2e-11   # u = (nu zp1 - nu0)/dnu cancellation noise, both sides
+    assert np.abs(d2[:, 1] - noise - np.prod(parts, axis=0)).max() < 2e-11
     assert np.array_equal(one, m1)
 
 
