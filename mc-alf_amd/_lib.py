@@ -10,7 +10,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmcalf_hip.so")
+LIB_PATH = os.environ.get("MCALF_HIP_LIB") or os.path.join(_HERE, "csrc", "libmcalf_hip.so")
 
 MCALF_OK = 0
 MCALF_CONV_WRAP_NUMPY = 0

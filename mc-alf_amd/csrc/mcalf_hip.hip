@@ -27,9 +27,14 @@
 
 namespace mcalf {
 
-constexpr int kBlock = 256;
-constexpr int kClStride = 8;            // doubles per (component,line) record in LDS
-constexpr int kExtDefault = 4096;       // pixels (tile + halo) per workgroup: 32 KiB of LDS
+constexpr int kBlock = 512;
+constexpr int kPpt = 8;                 // pixels per thread: (tile + halo) <= kBlock * kPpt
+constexpr int kExtMax = kBlock * kPpt;  // 4096 pixels = 32 KiB of LDS
+constexpr int kWaves = kBlock / 64;
+constexpr int kRecStride = 8;           // doubles per (component,line) record in LDS
+constexpr int kTabPad = VT_NTOT + 2;    // folded table in LDS: zone0 shifted by one to stay 16-B aligned
+constexpr int kZ0Lds = VT_Z0_OFF + 1;
+constexpr int kTileSlack = 16;           // zero-filled entries past the halo (sliding-window over-read)
 constexpr size_t kLdsBudget = 64 * 1024;
 constexpr double kCcgs = 2.9979245e10;  // hires_fitter.py:66
 constexpr double kFwhmToSigma = 2.354820;   // hires_fitter.py:454
@@ -55,12 +60,20 @@ struct KArgs {
     double* out;            // logL / chi2 [batch]   (written directly when ntiles == 1)
     double* model;          // [batch][npix] or nullptr
     const LineDev* lines;   // [nlines] then the filler line at [nlines]
-    const double* tabs;     // VT_L (384) then VT_K1 (384)
+    const double* tabs;     // T[VT_NY][VT_NTOT]
     int npix, ndim, ntiles, tile, n_cap, ncl_cap;
-    int nlines, ncompmax, nfill, startind, endind, freespecres, freecont, conv_mode;
+    int nlines, ncompmax, nfill, startind, endind, freespecres, freecont;
     int targonly, mode, jax_half, onecomp_fill;
     double specres_fixed, contval_fixed, velstep, log2pi;
 };
+
+// LDS flux tile: one pad double per 32 entries makes the stride-8 (8 outputs per lane) window
+// reads of the convolution bank-conflict free; row-contiguous accesses stay conflict free.
+__device__ __forceinline__ int tile_pos(int i) { return i + (i >> 5); }
+__host__ __device__ constexpr int tile_doubles(int ext) {
+    const int t = ext + kTileSlack + ((ext + kTileSlack) >> 5) + 1;
+    return t > VT_NY * VT_NTOT ? t : VT_NY * VT_NTOT;      // the region doubles as the T table
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -68,13 +81,26 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Sum over the workgroup, result in every thread; fixed order (deterministic).
+__device__ __forceinline__ double block_sum(double v, double* scratch, int tid) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) scratch[tid >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) s += scratch[w];
+    __syncthreads();
+    return s;
+}
+
 __device__ __forceinline__ double finalize_value(int mode, double sum, double nnz) {
     if (mode == kModeChi2) return (nnz == 0.0) ? INFINITY : sum;   // hires_fitter.py:241-246
     return -0.5 * sum;                                             // hires_fitter.py:294
 }
 
-// Record layout per (component,line): [A, B, y2, Kyt, y, ey2, K, flag]
-//   u = nu*A - B;  wing: tau += Kyt * t*(M1 - q(M3 - q M5));  core: tau += K * H_core(x, y)
+// Record per (component,line): [A, B, x2c, y, K, Kyt, flag, 0]
+//   u = nu*A - B;  tau += K H(u, y);  Kyt = K y / sqrt(pi) scales the wing polynomials;
+//   x2c: below it the core table (with exp(-x^2)) is used;  flag != 0 -> general path.
 __device__ inline void build_line_record(double* rec, double logN, double z, double b_kms, const LineDev& ln) {
     const double cold = pow(10.0, logN);                 // :357
     const double zp1 = z + 1.0;                          // :358
@@ -84,27 +110,28 @@ __device__ inline void build_line_record(double* rec, double logN, double z, dou
     const double K = cne / dnu;                          // :365  tau = cne * H / dnu
     rec[0] = zp1 / dnu;                                  // u = ((c/(lam/zp1)) - nujk)/dnu  (:362)
     rec[1] = ln.nujk / dnu;
-    rec[2] = a * a;
-    rec[3] = K * a * kInvSqrtPi;
-    rec[4] = a;
-    rec[5] = exp(a * a);
-    rec[6] = K;
+    rec[2] = core_limit_x2(K);
+    rec[3] = a;
+    rec[4] = K;
+    rec[5] = K * a * kInvSqrtPi;
     double flag = 0.0;
-    if (!(a <= kYFastMax) || !(a >= 0.0)) flag = 1.0;            // general path (also NaN)
-    else if (K * 1.6e-28 > 1e-18) flag = 2.0;                    // absurd columns: keep exp(-x^2) past |x| = 8
-    rec[7] = flag;
+    if (!(a <= kYFastMax) || !(a >= 0.0)) flag = 1.0;    // general path (also NaN)
+    else if (K * 1.6e-28 > 2e-17) flag = 1.0;            // absurd columns: exp(-x^2) matters past |x| = 8
+    rec[6] = flag;
+    rec[7] = 0.0;
 }
 
+#ifndef MCALF_MIN_WAVES
+#define MCALF_MIN_WAVES 4
+#endif
 template <bool kZeroPad>
-__global__ __launch_bounds__(kBlock) void mcalf_fused_kernel(const KArgs a) {
+__global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {
     extern __shared__ __align__(16) double smem[];
-    double* sTabL = smem;                              // 384
-    double* sTabK = sTabL + VT_NINT * VT_LSTRIDE;      // 384
-    double* sCl = sTabK + VT_NINT * VT_LSTRIDE;        // ncl_cap * 8
-    double* sW = sCl + a.ncl_cap * kClStride;          // 2 n_cap + 1
-    double* sRed = sW + (2 * a.n_cap + 1);             // 16
-    double* sF = sRed + 16;                            // tile + 2 n_cap
-    __shared__ double sh_bot;
+    double* sTab = smem;                                   // 2 buffers of kTabPad
+    double* sRec = sTab + 2 * kTabPad;                     // ncl_cap * 8
+    double* sW = sRec + a.ncl_cap * kRecStride;            // taps, zero-padded to a multiple of 8
+    double* sRed = sW + (2 * a.n_cap + 8);                 // 2 * kWaves
+    double* sF = sRed + 2 * kWaves;                        // tile_doubles(tile + 2 n_cap)
 
     const int tid = threadIdx.x;
     const int s = blockIdx.x / a.ntiles;
@@ -112,7 +139,13 @@ __global__ __launch_bounds__(kBlock) void mcalf_fused_kernel(const KArgs a) {
     const int rowlen = (a.mode == kModeOneComp) ? 5 : a.ndim;
     const double* p = a.P + (size_t)s * rowlen;
 
-    for (int i = tid; i < 2 * VT_NINT * VT_LSTRIDE; i += kBlock) sTabL[i] = a.tabs[i];
+    // The universal table T lives in the LDS region that later holds the flux tile (T is dead once
+    // the component loop ends).  Each thread folds ONE coefficient slot per line.
+    double* sT = sF;
+    for (int i = tid; i < VT_NY * VT_NTOT; i += kBlock) sT[i] = a.tabs[i];
+    const bool hasCoef = tid < VT_NTOT;
+    const int coefPos = tid + (tid >= VT_Z0_OFF ? 1 : 0);
+    const bool coreCoef = tid < VT_NCORE;
 
     // ---- 1. decode the parameter vector ---------------------------------------------------
     double R, cont;
@@ -127,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void mcalf_fused_kernel(const KArgs a) {
         cont = a.freecont ? (a.freespecres ? p[1] : p[0]) : a.contval_fixed;   // :419-425
         const double ncv = p[a.startind];
         // numpy path: int() truncates (:428); JAX path: floor (:616)
-        double nct = kZeroPad ? floor(ncv) : trunc(ncv);
+        const double nct = kZeroPad ? floor(ncv) : trunc(ncv);
         nc = (nct >= 1.0) ? ((nct >= (double)a.ncompmax) ? a.ncompmax : (int)nct) : 0;
         nfill_eff = a.targonly ? 0 : a.nfill;           // :437
     }
@@ -152,7 +185,7 @@ __global__ __launch_bounds__(kBlock) void mcalf_fused_kernel(const KArgs a) {
             logN = q[0]; z = q[1]; b = q[2];
             ln = a.lines + a.nlines;
         }
-        build_line_record(sCl + cl * kClStride, logN, z, b, *ln);
+        build_line_record(sRec + cl * kRecStride, logN, z, b, *ln);
     }
 
     // ---- LSF taps --------------------------------------------------------------------------
@@ -168,6 +201,7 @@ __global__ __launch_bounds__(kBlock) void mcalf_fused_kernel(const KArgs a) {
     } else {
         n = 0;
     }
+    double gsum = 0.0;
     for (int k = tid; k <= 2 * n; k += kBlock) {
         const double dk = (double)(k - n);
         double g;
@@ -175,77 +209,147 @@ __global__ __launch_bounds__(kBlock) void mcalf_fused_kernel(const KArgs a) {
         else if (n == 0) g = 1.0;
         else g = exp(-0.5 * dk * dk / (sigma * sigma)) / (sqrt(2.0 * M_PI) * sigma);  // Gaussian1DKernel
         sW[k] = g;
+        gsum += g;
     }
-    __syncthreads();
-    if (tid == 0) {
-        double ssum = 0.0;
-        for (int k = 0; k <= 2 * n; ++k) ssum += sW[k];
-        double bot = 0.0;
-        for (int k = 0; k <= 2 * n; ++k) {           // normalise (astropy normalize_kernel / :670)
-            const double w = sW[k] / ssum;
-            sW[k] = w;
-            bot += w;
-        }
-        sh_bot = kZeroPad ? 1.0 : bot;               // astropy divides by the tap sum it accumulated
+    gsum = block_sum(gsum, sRed, tid);               // (also publishes sRec / sW)
+    double wsum = 0.0;
+    for (int k = tid; k <= 2 * n; k += kBlock) {     // normalise (astropy normalize_kernel / :670)
+        const double w = sW[k] / gsum;
+        sW[k] = w;
+        wsum += w;
     }
-    __syncthreads();
+    // astropy's C loop divides by the tap sum it accumulates next to the data sum
+    const int ntap8 = (2 * n + 1 + 7) & ~7;
+    for (int k = 2 * n + 1 + tid; k < ntap8; k += kBlock) sW[k] = 0.0;
+    const double bot = kZeroPad ? 1.0 : block_sum(wsum, sRed, tid);
+    if (kZeroPad) __syncthreads();
 
-    // ---- 2. tau -> flux into the LDS tile ---------------------------------------------------
+    // ---- 2. tau for this thread's pixels ----------------------------------------------------
     const int t0 = tileIdx * a.tile;
     const int tlen = min(a.tile, a.npix - t0);
     const int ext0 = t0 - n;
     const int extCount = tlen + 2 * n;
-    for (int idx = tid; idx < extCount; idx += kBlock) {
+    double nu[kPpt], tau[kPpt];
+#pragma unroll
+    for (int j = 0; j < kPpt; ++j) {
+        const int idx = tid + j * kBlock;
         int e = ext0 + idx;
-        double fl;
-        if (kZeroPad && (e < 0 || e >= a.npix)) {
-            fl = 0.0;                                  // jnp.convolve 'same' zero padding (:674)
-        } else {
-            if (e < 0 || e >= a.npix) {                // astropy boundary='wrap'
-                e %= a.npix;
-                if (e < 0) e += a.npix;
-            }
-            const double nu = a.nu[e];
-            double tau = 0.0;
-            for (int c = 0; c < ncl; ++c) {
-                const double* rec = sCl + c * kClStride;
-                const double u = fma(nu, rec[0], -rec[1]);
-                const double x2 = u * u;
-                const double flag = rec[7];
-                if (flag == 1.0) {
-                    tau = fma(rec[6], hjert_general(fabs(u), rec[4]), tau);
-                } else if (x2 >= kX2Core) {
-                    tau = fma(rec[3], hjert_wing_scaled(x2, rec[2]), tau);
-                    if (flag == 2.0 && x2 < 745.0) tau = fma(rec[6], exp(-x2), tau);
-                } else {
-                    tau = fma(rec[6], hjert_core(fabs(u), x2, rec[4], rec[2], rec[5], sTabL, sTabK), tau);
-                }
-            }
-            fl = exp(-tau);                            // :377 (product of exp == exp of sum)
+        bool zero = false;
+        if (e < 0 || e >= a.npix) {
+            if (kZeroPad) { zero = true; e = 0; }            // jnp.convolve 'same' zero padding (:674)
+            else { e %= a.npix; if (e < 0) e += a.npix; }    // astropy boundary='wrap'
         }
-        sF[idx] = fl;
+        nu[j] = a.nu[e];
+        tau[j] = (zero && idx < extCount) ? INFINITY : 0.0;  // exp(-inf) = 0
     }
+
+    int buf = 0;
+#ifdef MCALF_ABL_NOLOOP   // ablation builds only (tools/ablate.sh); never defined in the product build
+    const int ncl_run = 0;
+#else
+    const int ncl_run = ncl;
+#endif
+    for (int cl = 0; cl < ncl_run; ++cl) {
+        const double* rec = sRec + cl * kRecStride;
+        const double A = rec[0], B = rec[1], x2c = rec[2], y = rec[3], K = rec[4], Kyt = rec[5];
+        const bool general = rec[6] != 0.0;
+        double* tab = sTab + buf * kTabPad;
+        if (hasCoef) {
+            double Tn[VT_NY];
+#pragma unroll
+            for (int nn = 0; nn < VT_NY; ++nn) Tn[nn] = sT[nn * VT_NTOT + tid];
+            tab[coefPos] = fold_coef(Tn, y, coreCoef ? K : Kyt);
+        }
+        __syncthreads();
+        buf ^= 1;
+        if (general) {
+#pragma unroll 1
+            for (int j = 0; j < kPpt; ++j) {
+                const double u = fma(nu[j], A, -B);
+                tau[j] = fma(K, hjert_general(fabs(u), y), tau[j]);
+            }
+            continue;
+        }
+        double c0[VT_WDEG + 1];
+#pragma unroll
+        for (int k = 0; k <= VT_WDEG; ++k) c0[k] = tab[kZ0Lds + k];
+#pragma unroll
+        for (int j = 0; j < kPpt; ++j) {
+            const double u = fma(nu[j], A, -B);
+            const double x2 = u * u;
+            if (x2 >= x2c) {
+                const double t = fast_rcp(x2);
+                double P;
+                if (x2 >= kX2Wing) {
+                    P = c0[VT_WDEG];
+#pragma unroll
+                    for (int k = VT_WDEG - 1; k >= 0; --k) P = fma(P, t, c0[k]);
+                } else {
+                    const double sv = fma(t, VT_Z1_A, VT_Z1_B);
+                    const double* c1 = tab + VT_Z1_OFF;
+                    P = c1[VT_WDEG];
+#pragma unroll
+                    for (int k = VT_WDEG - 1; k >= 0; --k) P = fma(P, sv, c1[k]);
+                }
+                tau[j] = fma(t, P, tau[j]);
+            } else {
+                const double x = fabs(u);
+                int jx = (int)(x * 4.0);
+                jx = min(max(jx, 0), VT_NINT - 1);
+                const double sv = fma(x, 8.0, -(double)(2 * jx + 1));
+                const double* cc = tab + jx * VT_CSTRIDE;
+                double P = cc[VT_CDEG];
+#pragma unroll
+                for (int k = VT_CDEG - 1; k >= 0; --k) P = fma(P, sv, cc[k]);
+                tau[j] += P;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kPpt; ++j) {
+        const int idx = tid + j * kBlock;
+        if (idx < extCount) sF[tile_pos(idx)] = exp(-tau[j]);    // :377 (product of exp == exp of sum)
+    }
+    if (tid < kTileSlack) sF[tile_pos(extCount + tid)] = 0.0;
     __syncthreads();
 
     // ---- 3+4. convolution, continuum, likelihood terms -------------------------------------
-    const double ibot = sh_bot;
+    // Register sliding window: this thread owns outputs base..base+7; per tap one new flux value
+    // and one (broadcast) weight are read from LDS for eight FMAs.
     double acc = 0.0, nnz = 0.0;
-    for (int i = tid; i < tlen; i += kBlock) {
-        const int pix = t0 + i;
-        double top = 0.0;
-        const double* f = sF + i;
-        for (int k = 0; k <= 2 * n; ++k) top = fma(f[k], sW[2 * n - k], top);
-        double m = kZeroPad ? top : top / ibot;
-        if (kZeroPad && (pix < n || pix >= a.npix - n)) m = f[n];     // :677-681 edge reset
-        m *= cont;                                                     // :447 / :683
-        if (bad) m = NAN;
-        if (a.model) a.model[(size_t)s * a.npix + pix] = m;
-        if (a.mode == kModeLogL || a.mode == kModeChi2) {
-            const double d = a.obj[pix] - m;
-            double term = a.ispec2[pix] * (d * d);
-            if (a.mode == kModeLogL) term = (term - a.lgis[pix]) + a.log2pi;  // :294
-            if (!isnan(term)) acc += term;                                     // np.nansum
-            if (m != 0.0) nnz += 1.0;
+    const int base = 8 * tid;
+    if (base < tlen) {
+        double win[8], top[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { win[m] = sF[tile_pos(base + m)]; top[m] = 0.0; }
+        for (int q0 = 0; q0 < ntap8; q0 += 8) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const double w = sW[q0 + r];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) top[m] = fma(win[(m + r) & 7], w, top[m]);
+                win[r] = sF[tile_pos(base + q0 + r + 8)];
+            }
+        }
+        const double ibot = 1.0 / bot;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int i = base + m;
+            if (i < tlen) {
+                const int pix = t0 + i;
+                double mval = kZeroPad ? top[m] : top[m] * ibot;
+                if (kZeroPad && (pix < n || pix >= a.npix - n)) mval = sF[tile_pos(i + n)];   // :677-681 edge reset
+                mval *= cont;                                                                  // :447 / :683
+                if (bad) mval = NAN;
+                if (a.model) a.model[(size_t)s * a.npix + pix] = mval;
+                if (a.mode == kModeLogL || a.mode == kModeChi2) {
+                    const double d = a.obj[pix] - mval;
+                    double term = a.ispec2[pix] * (d * d);
+                    if (a.mode == kModeLogL) term = (term - a.lgis[pix]) + a.log2pi;  // :294
+                    if (!isnan(term)) acc += term;                                     // np.nansum
+                    if (mval != 0.0) nnz += 1.0;
+                }
+            }
         }
     }
     if (a.mode == kModeModel || a.mode == kModeOneComp) return;
@@ -253,11 +357,12 @@ __global__ __launch_bounds__(kBlock) void mcalf_fused_kernel(const KArgs a) {
     acc = wave_sum(acc);
     nnz = wave_sum(nnz);
     const int wave = tid >> 6, lane = tid & 63;
-    if (lane == 0) { sRed[wave] = acc; sRed[4 + wave] = nnz; }
+    if (lane == 0) { sRed[wave] = acc; sRed[kWaves + wave] = nnz; }
     __syncthreads();
     if (tid == 0) {
-        const double ssum = ((sRed[0] + sRed[1]) + sRed[2]) + sRed[3];
-        const double scnt = ((sRed[4] + sRed[5]) + sRed[6]) + sRed[7];
+        double ssum = 0.0, scnt = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { ssum += sRed[w]; scnt += sRed[kWaves + w]; }
         if (a.ntiles == 1) {
             a.out[s] = finalize_value(a.mode, ssum, scnt);
         } else {
@@ -279,11 +384,8 @@ __global__ void mcalf_finalize_kernel(const double* partial, double* out, long b
 }
 
 __global__ void mcalf_hjert_kernel(const double* x, const double* y, long n, double* out, const double* tabs) {
-    __shared__ double sT[2 * VT_NINT * VT_LSTRIDE];
-    for (int i = threadIdx.x; i < 2 * VT_NINT * VT_LSTRIDE; i += blockDim.x) sT[i] = tabs[i];
-    __syncthreads();
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = hjert(x[i], y[i], sT, sT + VT_NINT * VT_LSTRIDE);
+    if (i < n) out[i] = hjert_folded(x[i], y[i], tabs);
 }
 
 __global__ void mcalf_scale_cube_kernel(const double* lo, const double* hi, const double* cube, long total,
@@ -384,11 +486,8 @@ static int grow(mcalf_ctx* ctx, T** ptr, size_t* cap, size_t need_elems) {
 }
 
 static int upload_tables(mcalf_ctx* ctx, double** d_tabs) {
-    std::vector<double> t(2 * VT_NINT * VT_LSTRIDE);
-    memcpy(t.data(), VT_L_HOST, sizeof(VT_L_HOST));
-    memcpy(t.data() + VT_NINT * VT_LSTRIDE, VT_K1_HOST, sizeof(VT_K1_HOST));
-    HIP_TRY(ctx, hipMalloc((void**)d_tabs, t.size() * sizeof(double)));
-    HIP_TRY(ctx, hipMemcpy(*d_tabs, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMalloc((void**)d_tabs, sizeof(VT_T_HOST)));
+    HIP_TRY(ctx, hipMemcpy(*d_tabs, VT_T_HOST, sizeof(VT_T_HOST), hipMemcpyHostToDevice));
     return MCALF_OK;
 }
 
@@ -452,23 +551,22 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         ctx->n_cap = (rmax > sp->velstep) ? (int)std::ceil(kKernelReach * sigma_max) : 0;
     }
     ctx->ncl_cap = std::max(1, ctx->ncompmax * ctx->nlines + ctx->nfill);
-    const size_t fixed_doubles = 2 * VT_NINT * VT_LSTRIDE + (size_t)ctx->ncl_cap * kClStride +
-                                 (2 * (size_t)ctx->n_cap + 1) + 16;
-    const size_t max_ext = (kLdsBudget / sizeof(double) > fixed_doubles) ? kLdsBudget / sizeof(double) - fixed_doubles : 0;
-    size_t ext = std::min<size_t>(kExtDefault, max_ext);
-    if (ext < 2 * (size_t)ctx->n_cap + 64)
-        ext = max_ext;   // long kernels: take all the LDS we allow ourselves
+    const size_t fixed_doubles = 2 * (size_t)kTabPad + (size_t)ctx->ncl_cap * kRecStride +
+                                 (2 * (size_t)ctx->n_cap + 8) + 2 * kWaves;
+    size_t ext = kExtMax;
+    while (ext > 0 && (fixed_doubles + tile_doubles((int)ext)) * sizeof(double) > kLdsBudget) ext -= 64;
     if (ext < 2 * (size_t)ctx->n_cap + 64)
         return set_err(ctx, MCALF_ERR_RANGE,
                        "LSF half-width %d px (specres_max %.3g km/s at %.3g km/s/px) with %d component-lines does not "
-                       "fit the %zu-byte LDS budget", ctx->n_cap, rmax, sp->velstep, ctx->ncl_cap, kLdsBudget);
+                       "fit a %d-pixel workgroup tile / the %zu-byte LDS budget", ctx->n_cap, rmax, sp->velstep,
+                       ctx->ncl_cap, kExtMax, kLdsBudget);
     long tile = (long)ext - 2 * ctx->n_cap;
     if (tile > ctx->npix) tile = ctx->npix;
     long ntiles = (ctx->npix + tile - 1) / tile;
     tile = (ctx->npix + ntiles - 1) / ntiles;      // balance
     ctx->tile = (int)tile;
     ctx->ntiles = (int)ntiles;
-    ctx->lds_bytes = (fixed_doubles + (size_t)tile + 2 * (size_t)ctx->n_cap) * sizeof(double);
+    ctx->lds_bytes = (fixed_doubles + (size_t)tile_doubles((int)tile + 2 * ctx->n_cap)) * sizeof(double);
 
     // spectrum arrays (float64 host arithmetic identical to the reference's numpy expressions)
     std::vector<double> nu(ctx->npix), is2(ctx->npix), lg(ctx->npix);
@@ -563,7 +661,7 @@ static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int
     a.n_cap = ctx->n_cap; a.ncl_cap = ctx->ncl_cap;
     a.nlines = ctx->nlines; a.ncompmax = ctx->ncompmax; a.nfill = ctx->nfill;
     a.startind = ctx->startind; a.endind = ctx->endind;
-    a.freespecres = ctx->freespecres; a.freecont = ctx->freecont; a.conv_mode = ctx->conv_mode;
+    a.freespecres = ctx->freespecres; a.freecont = ctx->freecont;
     a.targonly = targonly; a.mode = mode; a.jax_half = ctx->jax_half; a.onecomp_fill = onecomp_fill;
     a.specres_fixed = ctx->specres_fixed; a.contval_fixed = ctx->contval_fixed; a.velstep = ctx->velstep;
     a.log2pi = std::log(2.0 * M_PI);
