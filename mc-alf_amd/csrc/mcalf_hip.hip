@@ -32,8 +32,14 @@ constexpr int kPpt = 8;                 // pixels per thread: (tile + halo) <= k
 constexpr int kExtMax = kBlock * kPpt;  // 4096 pixels = 32 KiB of LDS
 constexpr int kWaves = kBlock / 64;
 constexpr int kRecStride = 8;           // doubles per (component,line) record in LDS
-constexpr int kTabPad = VT_NTOT + 2;    // folded table in LDS: zone0 shifted by one to stay 16-B aligned
+constexpr int kTabPad = VT_NTOT + 3;    // folded table in LDS: zone0 / zoneF shifted to stay 16-B aligned
 constexpr int kZ0Lds = VT_Z0_OFF + 1;
+constexpr int kZFLds = VT_ZF_OFF + 2;
+#ifndef MCALF_LINES_PER_SYNC
+#define MCALF_LINES_PER_SYNC 4
+#endif
+constexpr int kLinesPerSync = MCALF_LINES_PER_SYNC;
+static_assert(VT_NTOT <= 512 && (kZ0Lds % 2) == 0 && (kZFLds % 2) == 0 && (kTabPad % 2) == 0, "LDS table layout");
 constexpr int kTileSlack = 16;           // zero-filled entries past the halo (sliding-window over-read)
 constexpr size_t kLdsBudget = 64 * 1024;
 constexpr double kCcgs = 2.9979245e10;  // hires_fitter.py:66
@@ -81,6 +87,13 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Butterfly sum over the 64 lanes of a wave, result in every lane (no LDS, no barrier).
+__device__ __forceinline__ double wave_allsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 // Sum over the workgroup, result in every thread; fixed order (deterministic).
 __device__ __forceinline__ double block_sum(double v, double* scratch, int tid) {
     v = wave_sum(v);
@@ -98,11 +111,20 @@ __device__ __forceinline__ double finalize_value(int mode, double sum, double nn
     return -0.5 * sum;                                             // hires_fitter.py:294
 }
 
+// 10^x as exp(x ln 10) with the product carried in two doubles (about 1 ulp, a fraction of the cost of pow()).
+__device__ __forceinline__ double pow10_fast(double x) {
+    constexpr double kLn10Hi = 2.302585092994045901, kLn10Lo = -2.1707562233822494e-16;
+    const double p = x * kLn10Hi;
+    const double e = fma(x, kLn10Hi, -p) + x * kLn10Lo;
+    const double r = exp(p);
+    return fma(r, e, r);
+}
+
 // Record per (component,line): [A, B, x2c, y, K, Kyt, flag, 0]
 //   u = nu*A - B;  tau += K H(u, y);  Kyt = K y / sqrt(pi) scales the wing polynomials;
 //   x2c: below it the core table (with exp(-x^2)) is used;  flag != 0 -> general path.
 __device__ inline void build_line_record(double* rec, double logN, double z, double b_kms, const LineDev& ln) {
-    const double cold = pow(10.0, logN);                 // :357
+    const double cold = pow10_fast(logN);                // :357  10.0**N
     const double zp1 = z + 1.0;                          // :358
     const double dnu = (b_kms * 1e5) / ln.wrest_cm;      // :360 with :376's b*1e5
     const double a = ln.gamma / (4.0 * M_PI * dnu);      // :361
@@ -121,18 +143,76 @@ __device__ inline void build_line_record(double* rec, double logN, double z, dou
     rec[7] = 0.0;
 }
 
+// tau[j] += K H(u_j, y) for the thread's kPpt pixels and one (component,line); `tab` is the line's
+// folded table in LDS, `rec` its record.
+__device__ __forceinline__ void eval_line(const double* __restrict__ tab, const double* __restrict__ rec,
+                                          const double (&nu)[kPpt], double (&tau)[kPpt]) {
+    const double A = rec[0], B = rec[1], x2c = rec[2];
+    if (rec[6] != 0.0) {                              // general path (uniform over the workgroup)
+        const double y = rec[3], K = rec[4];
+#pragma unroll 1
+        for (int j = 0; j < kPpt; ++j) {
+            const double u = fma(nu[j], A, -B);
+            tau[j] = fma(K, hjert_general(fabs(u), y), tau[j]);
+        }
+        return;
+    }
+    double cF[VT_FDEG + 1];
+#pragma unroll
+    for (int k = 0; k <= VT_FDEG; ++k) cF[k] = tab[kZFLds + k];
+#pragma unroll
+    for (int j = 0; j < kPpt; ++j) {
+        const double u = fma(nu[j], A, -B);
+        const double x2 = u * u;
+        if (x2 >= kX2Far) {                           // |u| >= 16: most pixels
+            const double t = fast_rcp(x2);
+            double P = cF[VT_FDEG];
+#pragma unroll
+            for (int k = VT_FDEG - 1; k >= 0; --k) P = fma(P, t, cF[k]);
+            tau[j] = fma(t, P, tau[j]);
+        } else if (x2 >= x2c) {                       // exp(-u^2) gone: polynomial in 1/u^2
+            const double t = fast_rcp(x2);
+            const bool z0 = x2 >= kX2Wing;
+            const double sv = z0 ? t : fma(t, VT_Z1_A, VT_Z1_B);
+            const double* cw = tab + (z0 ? kZ0Lds : VT_Z1_OFF);
+            double P = cw[VT_WDEG];
+#pragma unroll
+            for (int k = VT_WDEG - 1; k >= 0; --k) P = fma(P, sv, cw[k]);
+            tau[j] = fma(t, P, tau[j]);
+        } else {                                      // core table (per-lane LDS gather)
+            const double x = fabs(u);
+            int jx = (int)(x * 4.0);
+            jx = min(max(jx, 0), VT_NINT - 1);
+            const double sv = fma(x, 8.0, -(double)(2 * jx + 1));
+            const double* cc = tab + jx * VT_CSTRIDE;
+            double P = cc[VT_CDEG];
+#pragma unroll
+            for (int k = VT_CDEG - 1; k >= 0; --k) P = fma(P, sv, cc[k]);
+            tau[j] += P;
+        }
+    }
+}
+
 #ifndef MCALF_MIN_WAVES
 #define MCALF_MIN_WAVES 4
 #endif
+#ifdef MCALF_STAMPS   // diagnostic builds only (tools/): per-workgroup phase timestamps
+__device__ unsigned long long g_stamps[8192 * 8];
+#define MCALF_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (k)] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MCALF_STAMP(k) do { } while (0)
+#endif
+
 template <bool kZeroPad>
 __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {
     extern __shared__ __align__(16) double smem[];
-    double* sTab = smem;                                   // 2 buffers of kTabPad
-    double* sRec = sTab + 2 * kTabPad;                     // ncl_cap * 8
+    double* sTab = smem;                                   // 2 x kLinesPerSync folded tables
+    double* sRec = sTab + 2 * kLinesPerSync * kTabPad;                     // ncl_cap * 8
     double* sW = sRec + a.ncl_cap * kRecStride;            // taps, zero-padded to a multiple of 8
     double* sRed = sW + (2 * a.n_cap + 8);                 // 2 * kWaves
     double* sF = sRed + 2 * kWaves;                        // tile_doubles(tile + 2 n_cap)
 
+    MCALF_STAMP(0);
     const int tid = threadIdx.x;
     const int s = blockIdx.x / a.ntiles;
     const int tileIdx = blockIdx.x - s * a.ntiles;
@@ -142,9 +222,15 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     // The universal table T lives in the LDS region that later holds the flux tile (T is dead once
     // the component loop ends).  Each thread folds ONE coefficient slot per line.
     double* sT = sF;
-    for (int i = tid; i < VT_NY * VT_NTOT; i += kBlock) sT[i] = a.tabs[i];
+    constexpr int kTRegs = (VT_NY * VT_NTOT + kBlock - 1) / kBlock;
+    double treg[kTRegs];                               // loads issued now, written to LDS after the set-up math
+#pragma unroll
+    for (int i = 0; i < kTRegs; ++i) {
+        const int idx = tid + i * kBlock;
+        treg[i] = (idx < VT_NY * VT_NTOT) ? a.tabs[idx] : 0.0;
+    }
     const bool hasCoef = tid < VT_NTOT;
-    const int coefPos = tid + (tid >= VT_Z0_OFF ? 1 : 0);
+    const int coefPos = tid + (tid >= VT_Z0_OFF ? 1 : 0) + (tid >= VT_ZF_OFF ? 1 : 0);
     const bool coreCoef = tid < VT_NCORE;
 
     // ---- 1. decode the parameter vector ---------------------------------------------------
@@ -201,29 +287,35 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     } else {
         n = 0;
     }
-    double gsum = 0.0;
-    for (int k = tid; k <= 2 * n; k += kBlock) {
-        const double dk = (double)(k - n);
-        double g;
-        if (kZeroPad) g = exp(-(dk * dk) / (2.0 * sigma * sigma));                  // :669
-        else if (n == 0) g = 1.0;
-        else g = exp(-0.5 * dk * dk / (sigma * sigma)) / (sqrt(2.0 * M_PI) * sigma);  // Gaussian1DKernel
-        sW[k] = g;
-        gsum += g;
-    }
-    gsum = block_sum(gsum, sRed, tid);               // (also publishes sRec / sW)
-    double wsum = 0.0;
-    for (int k = tid; k <= 2 * n; k += kBlock) {     // normalise (astropy normalize_kernel / :670)
-        const double w = sW[k] / gsum;
-        sW[k] = w;
-        wsum += w;
-    }
-    // astropy's C loop divides by the tap sum it accumulates next to the data sum
+    // Every wave computes the (few) taps itself, so the normalisation needs no workgroup barrier;
+    // wave 0 writes them.  astropy normalises the kernel by its sum and its C loop then divides by
+    // the tap sum it accumulates next to the data sum (`bot`); the JAX path only normalises (:670).
+    const int lane = tid & 63;
     const int ntap8 = (2 * n + 1 + 7) & ~7;
-    for (int k = 2 * n + 1 + tid; k < ntap8; k += kBlock) sW[k] = 0.0;
-    const double bot = kZeroPad ? 1.0 : block_sum(wsum, sRed, tid);
-    if (kZeroPad) __syncthreads();
+    const double inv2s2 = kZeroPad ? 1.0 / (2.0 * sigma * sigma) : 0.5 / (sigma * sigma);
+    const double amp = kZeroPad ? 1.0 : 1.0 / (sqrt(2.0 * M_PI) * sigma);          // Gaussian1DKernel amplitude
+    double gsum = 0.0;
+    for (int k = lane; k <= 2 * n; k += 64) {
+        const double dk = (double)(k - n);
+        gsum += (n == 0 && !kZeroPad) ? 1.0 : exp(-(dk * dk) * inv2s2) * amp;        // :669 / Gaussian1D
+    }
+    gsum = wave_allsum(gsum);
+    double wsum = 0.0;
+    for (int k = lane; k < ntap8; k += 64) {
+        const double dk = (double)(k - n);
+        const double g = (n == 0 && !kZeroPad) ? 1.0 : exp(-(dk * dk) * inv2s2) * amp;
+        const double w = (k <= 2 * n) ? g / gsum : 0.0;                              // zero-padded to 8
+        wsum += w;
+        if (tid < 64) sW[k] = w;
+    }
+    const double bot = kZeroPad ? 1.0 : wave_allsum(wsum);
+#pragma unroll
+    for (int i = 0; i < kTRegs; ++i) {
+        const int idx = tid + i * kBlock;
+        if (idx < VT_NY * VT_NTOT) sT[idx] = treg[i];
+    }
 
+    MCALF_STAMP(1);
     // ---- 2. tau for this thread's pixels ----------------------------------------------------
     const int t0 = tileIdx * a.tile;
     const int tlen = min(a.tile, a.npix - t0);
@@ -243,68 +335,38 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         tau[j] = (zero && idx < extCount) ? INFINITY : 0.0;  // exp(-inf) = 0
     }
 
+    __syncthreads();                                   // publishes sRec, sW, sT
+    MCALF_STAMP(2);
     int buf = 0;
-#ifdef MCALF_ABL_NOLOOP   // ablation builds only (tools/ablate.sh); never defined in the product build
+#ifdef MCALF_ABL_NOLOOP   // ablation builds only (tools/); never defined in the product build
     const int ncl_run = 0;
 #else
     const int ncl_run = ncl;
 #endif
-    for (int cl = 0; cl < ncl_run; ++cl) {
-        const double* rec = sRec + cl * kRecStride;
-        const double A = rec[0], B = rec[1], x2c = rec[2], y = rec[3], K = rec[4], Kyt = rec[5];
-        const bool general = rec[6] != 0.0;
-        double* tab = sTab + buf * kTabPad;
+    // kLinesPerSync lines are folded per workgroup barrier (their tables are double-buffered), which
+    // halves the barriers and averages the per-wave core/wing imbalance over more work.
+    for (int cl0 = 0; cl0 < ncl_run; cl0 += kLinesPerSync) {
+        double* tabs = sTab + buf * (kLinesPerSync * kTabPad);
         if (hasCoef) {
             double Tn[VT_NY];
 #pragma unroll
             for (int nn = 0; nn < VT_NY; ++nn) Tn[nn] = sT[nn * VT_NTOT + tid];
-            tab[coefPos] = fold_coef(Tn, y, coreCoef ? K : Kyt);
+#pragma unroll
+            for (int l = 0; l < kLinesPerSync; ++l) {
+                if (cl0 + l < ncl_run) {
+                    const double* rec = sRec + (cl0 + l) * kRecStride;
+                    tabs[l * kTabPad + coefPos] = fold_coef(Tn, rec[3], coreCoef ? rec[4] : rec[5]);
+                }
+            }
         }
         __syncthreads();
         buf ^= 1;
-        if (general) {
-#pragma unroll 1
-            for (int j = 0; j < kPpt; ++j) {
-                const double u = fma(nu[j], A, -B);
-                tau[j] = fma(K, hjert_general(fabs(u), y), tau[j]);
-            }
-            continue;
-        }
-        double c0[VT_WDEG + 1];
 #pragma unroll
-        for (int k = 0; k <= VT_WDEG; ++k) c0[k] = tab[kZ0Lds + k];
-#pragma unroll
-        for (int j = 0; j < kPpt; ++j) {
-            const double u = fma(nu[j], A, -B);
-            const double x2 = u * u;
-            if (x2 >= x2c) {
-                const double t = fast_rcp(x2);
-                double P;
-                if (x2 >= kX2Wing) {
-                    P = c0[VT_WDEG];
-#pragma unroll
-                    for (int k = VT_WDEG - 1; k >= 0; --k) P = fma(P, t, c0[k]);
-                } else {
-                    const double sv = fma(t, VT_Z1_A, VT_Z1_B);
-                    const double* c1 = tab + VT_Z1_OFF;
-                    P = c1[VT_WDEG];
-#pragma unroll
-                    for (int k = VT_WDEG - 1; k >= 0; --k) P = fma(P, sv, c1[k]);
-                }
-                tau[j] = fma(t, P, tau[j]);
-            } else {
-                const double x = fabs(u);
-                int jx = (int)(x * 4.0);
-                jx = min(max(jx, 0), VT_NINT - 1);
-                const double sv = fma(x, 8.0, -(double)(2 * jx + 1));
-                const double* cc = tab + jx * VT_CSTRIDE;
-                double P = cc[VT_CDEG];
-#pragma unroll
-                for (int k = VT_CDEG - 1; k >= 0; --k) P = fma(P, sv, cc[k]);
-                tau[j] += P;
-            }
+        for (int l = 0; l < kLinesPerSync; ++l) {
+            if (cl0 + l < ncl_run) eval_line(tabs + l * kTabPad, sRec + (cl0 + l) * kRecStride, nu, tau);
         }
     }
+    MCALF_STAMP(3);
 #pragma unroll
     for (int j = 0; j < kPpt; ++j) {
         const int idx = tid + j * kBlock;
@@ -313,6 +375,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     if (tid < kTileSlack) sF[tile_pos(extCount + tid)] = 0.0;
     __syncthreads();
 
+    MCALF_STAMP(4);
     // ---- 3+4. convolution, continuum, likelihood terms -------------------------------------
     // Register sliding window: this thread owns outputs base..base+7; per tap one new flux value
     // and one (broadcast) weight are read from LDS for eight FMAs.
@@ -352,17 +415,20 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             }
         }
     }
+    MCALF_STAMP(5);
     if (a.mode == kModeModel || a.mode == kModeOneComp) return;
 
     acc = wave_sum(acc);
     nnz = wave_sum(nnz);
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = tid >> 6;
     if (lane == 0) { sRed[wave] = acc; sRed[kWaves + wave] = nnz; }
     __syncthreads();
     if (tid == 0) {
         double ssum = 0.0, scnt = 0.0;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) { ssum += sRed[w]; scnt += sRed[kWaves + w]; }
+        MCALF_STAMP(6);
+        MCALF_STAMP(7);
         if (a.ntiles == 1) {
             a.out[s] = finalize_value(a.mode, ssum, scnt);
         } else {
@@ -551,7 +617,7 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         ctx->n_cap = (rmax > sp->velstep) ? (int)std::ceil(kKernelReach * sigma_max) : 0;
     }
     ctx->ncl_cap = std::max(1, ctx->ncompmax * ctx->nlines + ctx->nfill);
-    const size_t fixed_doubles = 2 * (size_t)kTabPad + (size_t)ctx->ncl_cap * kRecStride +
+    const size_t fixed_doubles = 2 * (size_t)kLinesPerSync * kTabPad + (size_t)ctx->ncl_cap * kRecStride +
                                  (2 * (size_t)ctx->n_cap + 8) + 2 * kWaves;
     size_t ext = kExtMax;
     while (ext > 0 && (fixed_doubles + tile_doubles((int)ext)) * sizeof(double) > kLdsBudget) ext -= 64;
@@ -790,3 +856,9 @@ extern "C" int mcalf_voigt_hjerting(const double* x, const double* y, int64_t n,
     if (dtabs) (void)hipFree(dtabs);
     return rc;
 }
+
+#ifdef MCALF_STAMPS
+extern "C" int mcalf_diag_read_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif

@@ -16,7 +16,8 @@ Layout of T[n][idx], n = 0..6, idx in [0, VT_NTOT):
   core   idx = j*12 + k, j < 32 : |x| in [j/4, (j+1)/4), polynomial in s = 8|x| - (2j+1), coefficient k
          T[n] = Chebyshev-interpolant monomial coefficients of h_n
   zone1  idx = 384 + k, k < 11  : 6 <= |x| < 8, variable s = VT_Z1_A * t + VT_Z1_B in [-1,1], t = 1/x^2
-  zone0  idx = 395 + k, k < 11  : |x| >= 8, variable t
+  zone0  idx = 395 + k, k < 11  : 8 <= |x| < 16, variable t
+  zoneF  idx = 406 + k, k < 7   : |x| >= 16, variable t, degree 6
          exp(-x^2) is dropped (the kernel only enters these zones where K exp(-x^2) < 2e-17):
          H = (y t/sqrt(pi)) [Q1 - y^2 Q3 + y^4 Q5](t),  Q1 = sqrt(pi) x^2 h_1,
          Q3 = -sqrt(pi) x^2 h_3,  Q5 = sqrt(pi) x^2 h_5;   T[0] = Q1, T[2] = -Q3, T[4] = Q5, odd rows 0.
@@ -38,7 +39,10 @@ XMID = 6                       # zone1 covers [XMID, XCORE)
 NCORE = NINT * (CDEG + 1)
 Z1_OFF = NCORE
 Z0_OFF = NCORE + (WDEG + 1)
-NTOT = NCORE + 2 * (WDEG + 1)
+FDEG = 6                       # far-wing polynomial degree (|x| >= XFAR)
+XFAR = 16
+ZF_OFF = NCORE + 2 * (WDEG + 1)
+NTOT = ZF_OFF + (FDEG + 1)
 
 
 def w_derivs(x, nmax):
@@ -130,6 +134,10 @@ def build():
         mono0 = mono_shift(cheb_to_mono(cheb_coefs(lambda t, wh=which: q_of(t, wh), 0, t_lo, WDEG)), t_lo / 2, t_lo / 2)
         for k in range(WDEG + 1):
             T[row][Z0_OFF + k] = sign * mono0[k]
+        t_far = mp.mpf(1) / (XFAR * XFAR)
+        monof = mono_shift(cheb_to_mono(cheb_coefs(lambda t, wh=which: q_of(t, wh), 0, t_far, FDEG)), t_far / 2, t_far / 2)
+        for k in range(FDEG + 1):
+            T[row][ZF_OFF + k] = sign * monof[k]
     return T, (1 / th, -tc / th)
 
 
@@ -149,6 +157,9 @@ def main(out_path):
     L.append(f"#define VT_NCORE {NCORE}")
     L.append(f"#define VT_Z1_OFF {Z1_OFF}")
     L.append(f"#define VT_Z0_OFF {Z0_OFF}")
+    L.append(f"#define VT_ZF_OFF {ZF_OFF}")
+    L.append(f"#define VT_FDEG {FDEG}")
+    L.append(f"#define VT_XFAR {float(XFAR)!r}")
     L.append(f"#define VT_NTOT {NTOT}")
     L.append(f"#define VT_Z1_A {float(z1a)!r}")
     L.append(f"#define VT_Z1_B {float(z1b)!r}")

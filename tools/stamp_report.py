@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-workgroup phase timestamps of the fused kernel (needs a -DMCALF_STAMPS build:
+MCALF_HIP_LIB=build/abl/stamps.so python tools/stamp_report.py)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mcalf_amd
+from mcalf_amd import _lib, workloads
+
+
+def synth(kw, p):
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        return fit.reconstruct_spec(np.asarray(p, float))
+
+
+kw, batch, seed = workloads.config(sys.argv[1] if len(sys.argv) > 1 else "B", synth)
+P = workloads.draw_P(kw, batch, np.random.default_rng(seed))
+fit = mcalf_amd.als_fitter(None, **kw)
+for _ in range(3):
+    fit.loglike_batch(P)
+lib = _lib.load()
+n = batch * fit.info.ntiles
+buf = (C.c_ulonglong * (n * 8))()
+lib.mcalf_diag_read_stamps.argtypes = [C.c_void_p, C.c_int]
+assert lib.mcalf_diag_read_stamps(buf, n * 8) == 0
+st = np.array(buf, dtype=np.uint64).reshape(n, 8).astype(np.int64)
+names = ["start", "setup(decode,records,taps)", "nu loads", "component loop", "exp+flux store", "conv+terms", "reduce"]
+print("workgroups", n)
+for k in range(2, 7):
+    d = st[:, k] - st[:, k - 1]
+    print("%-28s mean %9.0f  median %9.0f  max %9.0f cycles" % (names[k], d.mean(), np.median(d), d.max()))
+# global timeline from s_memrealtime (100 MHz): stamps 0 (start) and 7 (end)
+t0 = st[:, 0].min()
+start = (st[:, 0] - t0) * 10e-3   # us
+end = (st[:, 7] - t0) * 10e-3
+life = end - start
+print("kernel span %.1f us; WG lifetime mean %.1f us (min %.1f, max %.1f); sum(life)/512 slots = %.1f us"
+      % (end.max(), life.mean(), life.min(), life.max(), life.sum() / 512))
+print("start time percentiles [us]:", np.percentile(start, [0, 25, 50, 75, 100]).round(1).tolist())
+print("end   time percentiles [us]:", np.percentile(end, [0, 25, 50, 75, 90, 99, 100]).round(1).tolist())
+nb = P[:, 3::3][:, :8].sum(axis=1)
+print("corr(lifetime, sum b) = %.3f" % np.corrcoef(life, nb)[0, 1])
+ss = np.sort(start)
+print("sorted start times [us] every 64th:", ss[::64].round(1).tolist())
+o = np.argsort(start)
+print("blockIdx of first 16 starters:", o[:16].tolist())
+print("lifetimes of first-round (start<3us) mean %.1f, later mean %.1f; n_first=%d" % (life[start < 3].mean(), life[start >= 3].mean(), (start < 3).sum()))
