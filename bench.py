@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 import mcalf_amd  # noqa: E402
 from mcalf_amd import _lib, workloads  # noqa: E402
+from mcalf_amd import dist as mdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 peak
@@ -67,6 +68,9 @@ def main():
     ap.add_argument("--config", default="B", choices=["A", "B", "C", "E"])
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 = skip)")
+    ap.add_argument("--host-api", action="store_true",
+                    help="diagnostic: time the host-pointer entry (H2D of P and D2H of logL inside the step); "
+                         "never the headline value")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,8 +97,9 @@ def main():
     line_pix = float((nc * nlines + fit.nfill).sum()) * npix
 
     dP = torch.from_numpy(P_host).to(dev)
-    dlogL = torch.empty(batch, dtype=torch.float64, device=dev)
-    gathered = [torch.empty(batch, dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
+    plan = mdist.LogLGather(batch * world, dev)          # rows [rank*batch, (rank+1)*batch) are local
+    assert (plan.lo, plan.hi) == (rank * batch, (rank + 1) * batch)
+    dlogL = plan.local
     _lib.check(fit._lib.mcalf_reserve(fit._ctx, batch), fit._ctx)
     stream = torch.cuda.current_stream()
     st = C.c_void_p(stream.cuda_stream)
@@ -102,11 +107,14 @@ def main():
     ctx, pP, pL = fit._ctx, dP.data_ptr(), dlogL.data_ptr()
 
     def step():
+        if args.host_api:
+            fit.loglike_batch(P_host)
+            return
         rc = launch(ctx, pP, batch, pL, st)
         if rc:
             _lib.check(rc, ctx)
         if world > 1:
-            dist.gather(dlogL, gathered, dst=0)
+            plan.gather()                                # RCCL gather of the logL shards to rank 0
 
     def fence():
         if world > 1:
@@ -143,6 +151,14 @@ def main():
         alg_bytes = (8 * ndim + 8) * batch + 24 * npix
         alg_flops = 40.0 * line_pix + (31 + 4 * n_half) * npix * batch
         ach_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None                       # HBM bytes per launch from rocprofv3 PMC passes (offline, profiles/)
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+                tr = json.load(fh).get(args.config)
+            if tr and not args.batch:
+                traffic = tr["traffic_bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "component-pixel Voigt evals/s (sum_s ncomp_s * npix / t), logL batch on MI355X",
             "value": comp_pix_job * args.steps / elapsed,
@@ -150,7 +166,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", "entry": "host pointers (PCIe inclusive)" if args.host_api else "device pointers",
             "config": {"workload": f"BASELINE config {args.config}: CIV 1548/1550 synthetic spectrum" if args.config != "E"
                        else "BASELINE config E: HI 1215 damped", "batch_per_gpu": batch, "global_batch": batch * world,
                        "npix": npix, "ncomp": list(kw["ncomp"]), "nlines": nlines, "nfill": fit.nfill, "ndim": ndim,
@@ -160,7 +176,7 @@ def main():
             "line_pixel_evals_per_s": line_pix_job * args.steps / elapsed,
             "kernel_ms": kern_ms,
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mcalf_fused_kernel", "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "fused path is FP64-VALU bound, not HBM bound (SURVEY.md 8d); see roofline_valu"},
             "roofline_valu": {"bound": "fp64_valu", "achieved": alg_flops / (kern_ms * 1e-3) / 1e12,

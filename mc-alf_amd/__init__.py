@@ -6,7 +6,9 @@ The directory name contains a hyphen; `import mcalf_amd` (the alias module at th
 repository root) resolves to this package.
 """
 from . import _lib  # noqa: F401
+from . import dist  # noqa: F401
 from . import routines  # noqa: F401
+from . import workloads  # noqa: F401
 from .routines import hires_fitter  # noqa: F401
 from .routines.hires_fitter import als_fitter  # noqa: F401
 
