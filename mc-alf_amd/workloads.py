@@ -74,7 +74,11 @@ def config(name, synth=None):
 def bounds_of(kw):
     """Prior box implied by the kwargs, in the reference's parameter order
     (hires_fitter.py:184-198); mirrors als_fitter without needing a device."""
-    wl = kw["spectrum"][0]
+    wl = np.asarray(kw["spectrum"][0], dtype=float)
+    ok = np.zeros(wl.size, dtype=bool)                  # range selection, hires_fitter.py:75-82
+    for lo_w, hi_w in kw["fitrange"]:
+        ok |= (wl > lo_w) & (wl < hi_w)
+    wl = wl[ok]
     specres = list(np.atleast_1d(kw.get("specres", [7.0])))
     contval = list(np.atleast_1d(kw.get("contval", [1.0])))
     nmax = kw["ncomp"][1]

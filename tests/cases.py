@@ -6,13 +6,18 @@ from oracle import numpy_oracle as oracle
 
 
 def problem_from_kwargs(kw):
-    wl, flux, err = kw["spectrum"]
+    wl, flux, err = (np.asarray(a, dtype=float) for a in kw["spectrum"])
+    if kw.get("fitrange") is not None:                 # range selection, hires_fitter.py:75-82
+        ok = np.zeros(wl.size, dtype=bool)
+        for lo, hi in kw["fitrange"]:
+            ok |= (wl > lo) & (wl < hi)
+        wl, flux, err = wl[ok], flux[ok], err[ok]
     return oracle.Problem(
         wl, flux, err, kw["linepars"], tuple(kw["ncomp"]), nfill=kw.get("nfill", 0),
         specres=kw.get("specres", [7.0]), contval=kw.get("contval", [1.0]),
         Nrange=kw.get("Nrange", [11.5, 16]), brange=kw.get("brange", [1, 30]), zrange=kw.get("zrange"),
         Nrangefill=kw.get("Nrangefill", [11.5, 16]), brangefill=kw.get("brangefill", [1, 30]),
-        fitrange=kw.get("fitrange"))
+        fitrange=kw.get("fitrange"), velstep=kw.get("velstep"))
 
 
 def oracle_synth(kw, p):
