@@ -86,6 +86,11 @@ typedef struct {
     double contval_fixed;    /* continuum when !freecont                                     */
     int32_t conv_mode;       /* MCALF_CONV_*                                                 */
     int32_t device;          /* HIP device ordinal, or -1 for the current device             */
+    int32_t asymmlike;       /* 1: asymmetric veto of hires_fitter.py:296-303 in loglike      */
+    double asymm_n4;         /* gauss_cdf[1]: allowed count of (obj-model)/err > 4 before the
+                                0.01*npix grace (the reference draws it from an unseeded
+                                np.random.normal, :179-181, so it is an input here)          */
+    double asymm_n5;         /* gauss_cdf[2]: same for > 5                                    */
 } mcalf_spec;
 
 typedef struct {

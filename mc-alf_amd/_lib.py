@@ -43,6 +43,9 @@ class mcalf_spec(C.Structure):
         ("contval_fixed", C.c_double),
         ("conv_mode", C.c_int32),
         ("device", C.c_int32),
+        ("asymmlike", C.c_int32),
+        ("asymm_n4", C.c_double),
+        ("asymm_n5", C.c_double),
     ]
 
 

@@ -61,16 +61,18 @@ struct KArgs {
     const double* obj;      // [npix]
     const double* ispec2;   // [npix] 1/err^2
     const double* lgis;     // [npix] log(ispec2)
+    const double* err;      // [npix] obj_noise (asymmetric veto only)
     const double* P;        // [batch][ndim]  (mode OneComp: [batch][5])
-    double* partial;        // [batch][ntiles][2]  (sum, nonzero-count)
+    double* partial;        // [batch][ntiles][4]  (sum, nonzero-count, #resid>4, #resid>5)
     double* out;            // logL / chi2 [batch]   (written directly when ntiles == 1)
     double* model;          // [batch][npix] or nullptr
     const LineDev* lines;   // [nlines] then the filler line at [nlines]
     const double* tabs;     // T[VT_NY][VT_NTOT]
     int npix, ndim, ntiles, tile, n_cap, ncl_cap;
     int nlines, ncompmax, nfill, startind, endind, freespecres, freecont;
-    int targonly, mode, jax_half, onecomp_fill;
+    int targonly, mode, jax_half, onecomp_fill, asymm;
     double specres_fixed, contval_fixed, velstep, log2pi;
+    double veto4, veto5;    // asymmetric veto: allowed counts of resid > 4 / > 5 (threshold + grace)
 };
 
 // LDS flux tile: one pad double per 32 entries makes the stride-8 (8 outputs per lane) window
@@ -106,9 +108,11 @@ __device__ __forceinline__ double block_sum(double v, double* scratch, int tid) 
     return s;
 }
 
-__device__ __forceinline__ double finalize_value(int mode, double sum, double nnz) {
+__device__ __forceinline__ double finalize_value(int mode, double sum, double nnz, bool asymm, double c4,
+                                                 double c5, double veto4, double veto5) {
     if (mode == kModeChi2) return (nnz == 0.0) ? INFINITY : sum;   // hires_fitter.py:241-246
-    return -0.5 * sum;                                             // hires_fitter.py:294
+    if (asymm && (c5 > veto5 || c4 > veto4)) return -INFINITY;     // :296-303
+    return -0.5 * sum;                                             // :294
 }
 
 // 10^x as exp(x ln 10) with the product carried in two doubles (about 1 ulp, a fraction of the cost of pow()).
@@ -209,8 +213,8 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     double* sTab = smem;                                   // 2 x kLinesPerSync folded tables
     double* sRec = sTab + 2 * kLinesPerSync * kTabPad;                     // ncl_cap * 8
     double* sW = sRec + a.ncl_cap * kRecStride;            // taps, zero-padded to a multiple of 8
-    double* sRed = sW + (2 * a.n_cap + 8);                 // 2 * kWaves
-    double* sF = sRed + 2 * kWaves;                        // tile_doubles(tile + 2 n_cap)
+    double* sRed = sW + (2 * a.n_cap + 8);                 // 3 * kWaves
+    double* sF = sRed + 3 * kWaves;                        // tile_doubles(tile + 2 n_cap)
 
     MCALF_STAMP(0);
     const int tid = threadIdx.x;
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     // ---- 3+4. convolution, continuum, likelihood terms -------------------------------------
     // Register sliding window: this thread owns outputs base..base+7; per tap one new flux value
     // and one (broadcast) weight are read from LDS for eight FMAs.
-    double acc = 0.0, nnz = 0.0;
+    double acc = 0.0, nnz = 0.0, c4 = 0.0, c5 = 0.0;
     const int base = 8 * tid;
     if (base < tlen) {
         double win[8], top[8];
@@ -411,6 +415,11 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
                     if (a.mode == kModeLogL) term = (term - a.lgis[pix]) + a.log2pi;  // :294
                     if (!isnan(term)) acc += term;                                     // np.nansum
                     if (mval != 0.0) nnz += 1.0;
+                    if (a.asymm) {                                                     // :298-302
+                        const double resid = d / a.err[pix];
+                        if (resid > 4.0) c4 += 1.0;
+                        if (resid > 5.0) c5 += 1.0;
+                    }
                 }
             }
         }
@@ -422,6 +431,12 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     nnz = wave_sum(nnz);
     const int wave = tid >> 6;
     if (lane == 0) { sRed[wave] = acc; sRed[kWaves + wave] = nnz; }
+    double t4 = 0.0, t5 = 0.0;
+    if (a.asymm) {                                   // rare path: two more workgroup sums
+        __syncthreads();
+        t4 = block_sum(c4, sRed + 2 * kWaves, tid);
+        t5 = block_sum(c5, sRed + 2 * kWaves, tid);
+    }
     __syncthreads();
     if (tid == 0) {
         double ssum = 0.0, scnt = 0.0;
@@ -430,23 +445,24 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         MCALF_STAMP(6);
         MCALF_STAMP(7);
         if (a.ntiles == 1) {
-            a.out[s] = finalize_value(a.mode, ssum, scnt);
+            a.out[s] = finalize_value(a.mode, ssum, scnt, a.asymm != 0, t4, t5, a.veto4, a.veto5);
         } else {
-            a.partial[((size_t)s * a.ntiles + tileIdx) * 2 + 0] = ssum;
-            a.partial[((size_t)s * a.ntiles + tileIdx) * 2 + 1] = scnt;
+            double* pr = a.partial + ((size_t)s * a.ntiles + tileIdx) * 4;
+            pr[0] = ssum; pr[1] = scnt; pr[2] = t4; pr[3] = t5;
         }
     }
 }
 
-__global__ void mcalf_finalize_kernel(const double* partial, double* out, long batch, int ntiles, int mode) {
+__global__ void mcalf_finalize_kernel(const double* partial, double* out, long batch, int ntiles, int mode,
+                                      int asymm, double veto4, double veto5) {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= batch) return;
-    double sum = 0.0, cnt = 0.0;
+    double sum = 0.0, cnt = 0.0, c4 = 0.0, c5 = 0.0;
     for (int t = 0; t < ntiles; ++t) {
-        sum += partial[(s * ntiles + t) * 2 + 0];
-        cnt += partial[(s * ntiles + t) * 2 + 1];
+        const double* pr = partial + (s * ntiles + t) * 4;
+        sum += pr[0]; cnt += pr[1]; c4 += pr[2]; c5 += pr[3];
     }
-    out[s] = finalize_value(mode, sum, cnt);
+    out[s] = finalize_value(mode, sum, cnt, asymm != 0, c4, c5, veto4, veto5);
 }
 
 __global__ void mcalf_hjert_kernel(const double* x, const double* y, long n, double* out, const double* tabs) {
@@ -489,11 +505,13 @@ struct mcalf_ctx {
     int nlines = 0, ncompmax = 0, nfill = 0, freespecres = 0, freecont = 0, conv_mode = 0;
     int ndim = 0, startind = 0, endind = 0;
     double specres_fixed = 0, specres_max = 0, contval_fixed = 1, velstep = 0;
+    int asymm = 0;
+    double veto4 = 0, veto5 = 0;
     // geometry
     int n_cap = 0, tile = 0, ntiles = 0, ncl_cap = 0, jax_half = 0;
     size_t lds_bytes = 0;
     // device buffers
-    double *d_nu = nullptr, *d_obj = nullptr, *d_ispec2 = nullptr, *d_lgis = nullptr, *d_tabs = nullptr;
+    double *d_nu = nullptr, *d_obj = nullptr, *d_ispec2 = nullptr, *d_lgis = nullptr, *d_err = nullptr, *d_tabs = nullptr;
     LineDev* d_lines = nullptr;
     // workspaces (grown on demand)
     double *d_P = nullptr, *d_out = nullptr, *d_partial = nullptr, *d_model = nullptr, *d_bounds = nullptr;
@@ -566,7 +584,7 @@ extern "C" const char* mcalf_last_error(const mcalf_ctx* ctx) {
 extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_tabs, ctx->d_lines,
+    void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_err, ctx->d_tabs, ctx->d_lines,
                     ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -604,6 +622,9 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     ctx->specres_max = rmax;
     ctx->contval_fixed = sp->contval_fixed;
     ctx->velstep = sp->velstep;
+    ctx->asymm = sp->asymmlike ? 1 : 0;                                  // hires_fitter.py:296-303
+    ctx->veto4 = sp->asymm_n4 + 0.01 * (double)sp->npix;                 // gauss_cdf[1] + gracenum (:181,302)
+    ctx->veto5 = sp->asymm_n5 + 0.01 * (double)sp->npix;                 // gauss_cdf[2] + gracenum (:300)
     ctx->startind = ctx->freecont + ctx->freespecres;             // hires_fitter.py:169-174
     ctx->endind = ctx->startind + 3 * ctx->ncompmax + 1;          // :176
     ctx->ndim = ctx->endind + 3 * ctx->nfill;                     // :184-200
@@ -618,7 +639,7 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     }
     ctx->ncl_cap = std::max(1, ctx->ncompmax * ctx->nlines + ctx->nfill);
     const size_t fixed_doubles = 2 * (size_t)kLinesPerSync * kTabPad + (size_t)ctx->ncl_cap * kRecStride +
-                                 (2 * (size_t)ctx->n_cap + 8) + 2 * kWaves;
+                                 (2 * (size_t)ctx->n_cap + 8) + 3 * kWaves;
     size_t ext = kExtMax;
     while (ext > 0 && (fixed_doubles + tile_doubles((int)ext)) * sizeof(double) > kLdsBudget) ext -= 64;
     if (ext < 2 * (size_t)ctx->n_cap + 64)
@@ -655,11 +676,13 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_obj, nb));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ispec2, nb));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_lgis, nb));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_err, nb));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_lines, lines.size() * sizeof(LineDev)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_nu, nu.data(), nb, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_obj, sp->flux, nb, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_ispec2, is2.data(), nb, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_lgis, lg.data(), nb, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_err, sp->err, nb, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_lines, lines.data(), lines.size() * sizeof(LineDev), hipMemcpyHostToDevice));
     rc = upload_tables(ctx, &ctx->d_tabs);
     if (rc) return rc;
@@ -704,7 +727,7 @@ extern "C" int mcalf_reserve(mcalf_ctx* ctx, int64_t batch) {
     int rc;
     if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, (size_t)batch * std::max(ctx->ndim, 5)))) return rc;
     if ((rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
-    if ((rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 2))) return rc;
+    if ((rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4))) return rc;
     return MCALF_OK;
 }
 
@@ -716,11 +739,12 @@ static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int
         return set_err(ctx, MCALF_ERR_RANGE, "batch %lld too large", (long long)batch);
     const bool reduces = (mode == kModeLogL || mode == kModeChi2);
     if (reduces && ctx->ntiles > 1) {
-        int rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 2);
+        int rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4);
         if (rc) return rc;
     }
     KArgs a;
-    a.nu = ctx->d_nu; a.obj = ctx->d_obj; a.ispec2 = ctx->d_ispec2; a.lgis = ctx->d_lgis;
+    a.nu = ctx->d_nu; a.obj = ctx->d_obj; a.ispec2 = ctx->d_ispec2; a.lgis = ctx->d_lgis; a.err = ctx->d_err;
+    a.asymm = (mode == kModeLogL) ? ctx->asymm : 0; a.veto4 = ctx->veto4; a.veto5 = ctx->veto5;
     a.P = dP; a.partial = ctx->d_partial; a.out = d_out; a.model = d_model;
     a.lines = ctx->d_lines; a.tabs = ctx->d_tabs;
     a.npix = (int)ctx->npix; a.ndim = ctx->ndim; a.ntiles = ctx->ntiles; a.tile = ctx->tile;
@@ -740,7 +764,7 @@ static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int
     if (reduces && ctx->ntiles > 1) {
         const int fb = 256;
         hipLaunchKernelGGL(mcalf_finalize_kernel, dim3((unsigned)((batch + fb - 1) / fb)), dim3(fb), 0, stream,
-                           ctx->d_partial, d_out, (long)batch, ctx->ntiles, mode);
+                           ctx->d_partial, d_out, (long)batch, ctx->ntiles, mode, a.asymm, a.veto4, a.veto5);
         HIP_TRY(ctx, hipGetLastError());
     }
     return MCALF_OK;

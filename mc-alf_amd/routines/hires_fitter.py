@@ -77,13 +77,14 @@ class als_fitter:
 
     Extra keywords (all optional): `spectrum=(wl, flux, err)` arrays instead of a file;
     `linepars=[(wrest, f, gamma), ...]` instead of a linetools lookup; `velstep=`;
-    `conv_mode='numpy'|'jax'`; `device=` HIP ordinal.
+    `conv_mode='numpy'|'jax'`; `device=` HIP ordinal; `gauss_cdf=[n3, n4, n5]` to pin the
+    asymmetric-veto thresholds the reference draws at random.
     """
 
     def __init__(self, specfile, fitrange, fitlines, ncomp, nfill=0, specres=[7.0], contval=[1.0],
                  Nrange=[11.5, 16], brange=[1, 30], zrange=None, Nrangefill=[11.5, 16], brangefill=[1, 30],
                  wrangefill=None, coldef=['Wave', 'Flux', 'Err'], Gpriors=None, Asymmlike=False, debug=False,
-                 *, spectrum=None, linepars=None, velstep=None, conv_mode="numpy", device=-1):
+                 *, spectrum=None, linepars=None, velstep=None, conv_mode="numpy", device=-1, gauss_cdf=None):
         self.debug = debug
         self.specfile = specfile
         self.fitrange = fitrange
@@ -91,7 +92,7 @@ class als_fitter:
         self.Gpriors = Gpriors
         self.Asymmlike = Asymmlike
         if self.Asymmlike:
-            raise NotImplementedError("Asymmlike veto is a 'next' row (SURVEY.md section 8f); not built yet")
+            print("Running asymmetric likelihood")
         self.specres = list(np.atleast_1d(specres))
         self.contval = list(np.atleast_1d(contval))
         self.ncompmin = ncomp[0]
@@ -152,6 +153,14 @@ class als_fitter:
         self._lo = np.array([np.min(b) for b in self.bounds], dtype=float)
         self._hi = np.array([np.max(b) for b in self.bounds], dtype=float)
 
+        # Asymmetric-veto thresholds (hires_fitter.py:179-181): counts of a standard-normal draw
+        # above 3, 4, 5 sigma.  The reference's draw is unseeded; pass gauss_cdf=[n3, n4, n5] to pin it.
+        if gauss_cdf is None:
+            gauss = np.random.normal(size=len(self.obj))
+            gauss_cdf = [(gauss > 3).sum(), (gauss > 4).sum(), (gauss > 5).sum()]
+        self.gauss_cdf = [int(v) for v in gauss_cdf]
+        self.gracenum = 0.01 * len(self.obj)
+
         self.conv_mode = conv_mode
         self._ctx = None
         self._open_context(device)
@@ -200,6 +209,9 @@ class als_fitter:
         sp.contval_fixed = float(self.contval[0])
         sp.conv_mode = _lib.MCALF_CONV_SAME_EDGE_JAX if jax else _lib.MCALF_CONV_WRAP_NUMPY
         sp.device = int(device)
+        sp.asymmlike = int(bool(self.Asymmlike))
+        sp.asymm_n4 = float(self.gauss_cdf[1])
+        sp.asymm_n5 = float(self.gauss_cdf[2])
         ctx = C.c_void_p()
         _lib.check(lib.mcalf_create(C.byref(sp), C.byref(ctx)))
         self._ctx = ctx

@@ -34,7 +34,7 @@ def test_library_exports_every_symbol():
 
 def test_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.mcalf_line) == 24
-    assert C.sizeof(_lib.mcalf_spec) == 8 + 3 * 8 + 8 + 8 + 8 + 24 + 4 * 4 + 3 * 8 + 2 * 4
+    assert C.sizeof(_lib.mcalf_spec) == 8 + 3 * 8 + 8 + 8 + 8 + 24 + 4 * 4 + 3 * 8 + 2 * 4 + 8 + 2 * 8
     assert C.sizeof(_lib.mcalf_info_t) == 8 * 4 + 8 + 32
 
 
