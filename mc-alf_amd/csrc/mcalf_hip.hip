@@ -39,9 +39,16 @@ constexpr int kZFLds = VT_ZF_OFF + 2;
 #define MCALF_LINES_PER_SYNC 4
 #endif
 constexpr int kLinesPerSync = MCALF_LINES_PER_SYNC;
+static_assert(kBlock == 64 * VT_INODES, "one interpolation weight per thread");
 static_assert(VT_NTOT <= 512 && (kZ0Lds % 2) == 0 && (kZFLds % 2) == 0 && (kTabPad % 2) == 0, "LDS table layout");
 constexpr int kTileSlack = 16;           // zero-filled entries past the halo (sliding-window over-read)
-constexpr size_t kLdsBudget = 64 * 1024;
+constexpr size_t kLdsBudget = 78 * 1024;   // two workgroups per CU (160 KiB); needs the MaxDynamicSharedMemorySize attribute
+#ifndef MCALF_FAR_INTERP
+#define MCALF_FAR_INTERP 1
+#endif
+constexpr bool kFarInterp = MCALF_FAR_INTERP != 0;
+constexpr double kInterpC = 1.0e-3;        // interpolation error <= kInterpC (du/u0)^8 (measured 4.4e-4, tools/ + DESIGN.md)
+constexpr double kInterpTol = 1.0e-15;     // allowed optical-depth error per (line, pixel) from the interpolation
 constexpr double kCcgs = 2.9979245e10;  // hires_fitter.py:66
 constexpr double kFwhmToSigma = 2.354820;   // hires_fitter.py:454
 constexpr double kKernelReach = 3.0348;     // hires_fitter.py:458
@@ -68,10 +75,13 @@ struct KArgs {
     double* model;          // [batch][npix] or nullptr
     const LineDev* lines;   // [nlines] then the filler line at [nlines]
     const double* tabs;     // T[VT_NY][VT_NTOT]
+    const double* wtab;     // [64][8] Lagrange weights of the far-wing interpolation
+    const unsigned long long* segok;   // [ntiles] bit m: 64-pixel segment m of the tile may be interpolated
     int npix, ndim, ntiles, tile, n_cap, ncl_cap;
     int nlines, ncompmax, nfill, startind, endind, freespecres, freecont;
     int targonly, mode, jax_half, onecomp_fill, asymm;
     double specres_fixed, contval_fixed, velstep, log2pi;
+    double dnu_seg;         // largest |nu(first) - nu(last)| over the 64-pixel segments
     double veto4, veto5;    // asymmetric veto: allowed counts of resid > 4 / > 5 (threshold + grace)
 };
 
@@ -87,6 +97,13 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
+}
+
+// Tell the compiler a 64-bit value is wave-uniform (keeps it in SGPRs, branches on it are scalar).
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 // Butterfly sum over the 64 lanes of a wave, result in every lane (no LDS, no barrier).
@@ -124,10 +141,12 @@ __device__ __forceinline__ double pow10_fast(double x) {
     return fma(r, e, r);
 }
 
-// Record per (component,line): [A, B, x2c, y, K, Kyt, flag, 0]
+// Record per (component,line): [A, B, x2c, y, K, Kyt, flag, uthr]
 //   u = nu*A - B;  tau += K H(u, y);  Kyt = K y / sqrt(pi) scales the wing polynomials;
-//   x2c: below it the core table (with exp(-x^2)) is used;  flag != 0 -> general path.
-__device__ inline void build_line_record(double* rec, double logN, double z, double b_kms, const LineDev& ln) {
+//   x2c: below it the core table (with exp(-x^2)) is used;  flag != 0 -> general path;
+//   uthr: a 64-pixel segment whose pixels all have |u| >= uthr is evaluated at 8 nodes and interpolated.
+__device__ inline void build_line_record(double* rec, double logN, double z, double b_kms, const LineDev& ln,
+                                         double dnu_seg) {
     const double cold = pow10_fast(logN);                // :357  10.0**N
     const double zp1 = z + 1.0;                          // :358
     const double dnu = (b_kms * 1e5) / ln.wrest_cm;      // :360 with :376's b*1e5
@@ -144,13 +163,28 @@ __device__ inline void build_line_record(double* rec, double logN, double z, dou
     if (!(a <= kYFastMax) || !(a >= 0.0)) flag = 1.0;    // general path (also NaN)
     else if (K * 1.6e-28 > 2e-17) flag = 1.0;            // absurd columns: exp(-x^2) matters past |x| = 8
     rec[6] = flag;
-    rec[7] = 0.0;
+    // interpolation error kInterpC (du/u0)^8 Kyt/u0^2 <= kInterpTol  ->  u0^10 >= kInterpC Kyt du^8 / tol
+    const float du = (float)(rec[0] * dnu_seg);
+    const float du2 = du * du, du4 = du2 * du2;
+    const float q = (float)(kInterpC / kInterpTol) * (float)rec[5] * du4 * du4;
+    double uthr = (double)__powf(fmaxf(q, 1.0f), 0.1f) * 1.02;                 // 2 % margin over the float estimate
+    uthr = fmax(uthr, VT_XFAR);
+    rec[7] = (flag != 0.0 || !(uthr < 1e30)) ? INFINITY : uthr;               // never interpolate the general path
 }
+
+#ifdef MCALF_STAMPS   // diagnostic builds only (tools/): per-workgroup phase timestamps
+__device__ unsigned long long g_stamps[8192 * 8];
+__device__ unsigned long long g_dbg[4];   // [0] interpolated segments, [1] segments seen
+#define MCALF_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (k)] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MCALF_STAMP(k) do { } while (0)
+#endif
 
 // tau[j] += K H(u_j, y) for the thread's kPpt pixels and one (component,line); `tab` is the line's
 // folded table in LDS, `rec` its record.
 __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const double* __restrict__ rec,
-                                          const double (&nu)[kPpt], double (&tau)[kPpt]) {
+                                          const double (&nu)[kPpt], double (&tau)[kPpt], double nuNode,
+                                          double& farNode, unsigned long long segOk) {
     const double A = rec[0], B = rec[1], x2c = rec[2];
     if (rec[6] != 0.0) {                              // general path (uniform over the workgroup)
         const double y = rec[3], K = rec[4];
@@ -164,11 +198,39 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
     double cF[VT_FDEG + 1];
 #pragma unroll
     for (int k = 0; k <= VT_FDEG; ++k) cF[k] = tab[kZFLds + k];
+    // Node pass.  Lane l holds node (l & 7) of the wave's segment (l >> 3).  A segment whose eight
+    // nodes (both end pixels included, u monotonic along it) all have u >= uthr, or all u <= -uthr,
+    // is far-wing for this line everywhere: its contribution is evaluated at the nodes only and
+    // interpolated to the 64 pixels once, after the component loop.  `done` has bit 8 j set when
+    // segment j was handled that way.
+    unsigned long long done = 0;
+    if (kFarInterp) {
+        const double uthr = rec[7];
+        const double un = fma(nuNode, A, -B);
+        unsigned long long mp = __builtin_amdgcn_ballot_w64(un >= uthr);
+        unsigned long long mn = __builtin_amdgcn_ballot_w64(un <= -uthr);
+        mp &= mp >> 1; mp &= mp >> 2; mp &= mp >> 4;          // bit 8j = AND of byte j
+        mn &= mn >> 1; mn &= mn >> 2; mn &= mn >> 4;
+        done = uniform64((mp | mn) & segOk & 0x0101010101010101ULL);
+#ifdef MCALF_COUNT_INTERP
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&g_dbg[0], (unsigned long long)__popcll(done)); atomicAdd(&g_dbg[1], 8ULL); atomicAdd(&g_dbg[2], (unsigned long long)__popcll(segOk)); }
+#endif
+        if (done != 0) {                                      // wave-uniform
+            const unsigned long long lanes = done * 0xFFULL;  // byte j -> 0xFF: one bit per lane
+            const bool mine = (lanes >> (threadIdx.x & 63)) & 1ULL;
+            const double t = fast_rcp(fmax(un * un, kX2Far));
+            double P = cF[VT_FDEG];
+#pragma unroll
+            for (int k = VT_FDEG - 1; k >= 0; --k) P = fma(P, t, cF[k]);
+            farNode = fma(mine ? t : 0.0, P, farNode);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < kPpt; ++j) {
+        if ((done >> (8 * j)) & 1ULL) continue;       // whole segment interpolated (wave-uniform)
         const double u = fma(nu[j], A, -B);
         const double x2 = u * u;
-        if (x2 >= kX2Far) {                           // |u| >= 16: most pixels
+        if (x2 >= kX2Far) {                           // |u| >= 16
             const double t = fast_rcp(x2);
             double P = cF[VT_FDEG];
 #pragma unroll
@@ -200,13 +262,6 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
 #ifndef MCALF_MIN_WAVES
 #define MCALF_MIN_WAVES 4
 #endif
-#ifdef MCALF_STAMPS   // diagnostic builds only (tools/): per-workgroup phase timestamps
-__device__ unsigned long long g_stamps[8192 * 8];
-#define MCALF_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (k)] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define MCALF_STAMP(k) do { } while (0)
-#endif
-
 template <bool kZeroPad>
 __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {
     extern __shared__ __align__(16) double smem[];
@@ -214,7 +269,8 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     double* sRec = sTab + 2 * kLinesPerSync * kTabPad;                     // ncl_cap * 8
     double* sW = sRec + a.ncl_cap * kRecStride;            // taps, zero-padded to a multiple of 8
     double* sRed = sW + (2 * a.n_cap + 8);                 // 3 * kWaves
-    double* sF = sRed + 3 * kWaves;                        // tile_doubles(tile + 2 n_cap)
+    double* sWt = sRed + 3 * kWaves;                       // [8][64] interpolation weights, node-major
+    double* sF = sWt + 64 * VT_INODES;                        // tile_doubles(tile + 2 n_cap)
 
     MCALF_STAMP(0);
     const int tid = threadIdx.x;
@@ -233,6 +289,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         const int idx = tid + i * kBlock;
         treg[i] = (idx < VT_NY * VT_NTOT) ? a.tabs[idx] : 0.0;
     }
+    if (kFarInterp) sWt[(tid & 7) * 64 + (tid >> 3)] = a.wtab[tid];      // kBlock == 64 * VT_INODES
     const bool hasCoef = tid < VT_NTOT;
     const int coefPos = tid + (tid >= VT_Z0_OFF ? 1 : 0) + (tid >= VT_ZF_OFF ? 1 : 0);
     const bool coreCoef = tid < VT_NCORE;
@@ -275,7 +332,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             logN = q[0]; z = q[1]; b = q[2];
             ln = a.lines + a.nlines;
         }
-        build_line_record(sRec + cl * kRecStride, logN, z, b, *ln);
+        build_line_record(sRec + cl * kRecStride, logN, z, b, *ln, a.dnu_seg);
     }
 
     // ---- LSF taps --------------------------------------------------------------------------
@@ -321,10 +378,13 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
 
     MCALF_STAMP(1);
     // ---- 2. tau for this thread's pixels ----------------------------------------------------
+    // The tile always carries the full provisioned halo n_cap (so that its 64-pixel segments are the
+    // same for every sample); a sample with a shorter kernel simply starts `shift` entries in.
     const int t0 = tileIdx * a.tile;
     const int tlen = min(a.tile, a.npix - t0);
-    const int ext0 = t0 - n;
-    const int extCount = tlen + 2 * n;
+    const int ext0 = t0 - a.n_cap;
+    const int extCount = tlen + 2 * a.n_cap;
+    const int shift = a.n_cap - n;
     double nu[kPpt], tau[kPpt];
 #pragma unroll
     for (int j = 0; j < kPpt; ++j) {
@@ -337,6 +397,19 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         }
         nu[j] = a.nu[e];
         tau[j] = (zero && idx < extCount) ? INFINITY : 0.0;  // exp(-inf) = 0
+    }
+    // far-wing interpolation state: this lane's node pixel, the wave's interpolable segments
+    double nuNode = 0.0, farNode = 0.0;
+    unsigned long long segOk = 0;
+    if (kFarInterp) {
+        const int wv = tid >> 6, ln = tid & 63;
+        int e = ext0 + 64 * wv + kBlock * (ln >> 3) + VT_INTERP_NODES[ln & 7];
+        if (e < 0 || e >= a.npix) { e %= a.npix; if (e < 0) e += a.npix; }      // such segments are never interpolated
+        nuNode = a.nu[e];
+        const unsigned long long tileMask = a.segok[tileIdx];                  // bit m = segment m = wave + 8 j
+#pragma unroll
+        for (int j = 0; j < kPpt; ++j) segOk |= ((tileMask >> (wv + 8 * j)) & 1ULL) << (8 * j);
+        segOk = uniform64(segOk);
     }
 
     __syncthreads();                                   // publishes sRec, sW, sT
@@ -365,18 +438,39 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         }
         __syncthreads();
         buf ^= 1;
-#pragma unroll
+#pragma unroll 1                 // one copy of the (large) per-line body: keeps the loop inside the instruction cache
         for (int l = 0; l < kLinesPerSync; ++l) {
-            if (cl0 + l < ncl_run) eval_line(tabs + l * kTabPad, sRec + (cl0 + l) * kRecStride, nu, tau);
+            if (cl0 + l < ncl_run)
+                eval_line(tabs + l * kTabPad, sRec + (cl0 + l) * kRecStride, nu, tau, nuNode, farNode, segOk);
         }
     }
     MCALF_STAMP(3);
+    // Interpolate the far-wing node sums to the pixels (tau[j] += sum_k W[lane][k] F[segment j][node k]),
+    // then flux = exp(-tau) into the LDS tile.  The node sums travel through the (now dead) folded-table
+    // region, one 64-entry row per wave; the tile holds only the sample's own halo n (<= n_cap).
+    double wrow[VT_INODES];
+    double* sFar = sTab + (tid >> 6) * 64;
+    if (kFarInterp) {
+        __syncthreads();                               // every wave is done reading the folded tables
+        sFar[tid & 63] = farNode;
+#pragma unroll
+        for (int k = 0; k < VT_INODES; ++k) wrow[k] = sWt[k * 64 + (tid & 63)];
+    }
+    const int extTight = tlen + 2 * n;
 #pragma unroll
     for (int j = 0; j < kPpt; ++j) {
-        const int idx = tid + j * kBlock;
-        if (idx < extCount) sF[tile_pos(idx)] = exp(-tau[j]);    // :377 (product of exp == exp of sum)
+        double tj = tau[j];
+        if (kFarInterp) {
+            double add = 0.0;
+#pragma unroll
+            for (int k = 0; k < VT_INODES; ++k) add = fma(wrow[k], sFar[8 * j + k], add);
+            tj += add;
+        }
+        const int pos = tid + j * kBlock - shift;
+        if (pos >= 0 && pos < extTight) sF[tile_pos(pos)] = exp(-tj);    // :377 (product of exp == exp of sum)
+        __builtin_amdgcn_sched_barrier(0);             // keep the 8 broadcast reads of one j from piling up
     }
-    if (tid < kTileSlack) sF[tile_pos(extCount + tid)] = 0.0;
+    if (tid < kTileSlack) sF[tile_pos(extTight + tid)] = 0.0;
     __syncthreads();
 
     MCALF_STAMP(4);
@@ -513,6 +607,9 @@ struct mcalf_ctx {
     // device buffers
     double *d_nu = nullptr, *d_obj = nullptr, *d_ispec2 = nullptr, *d_lgis = nullptr, *d_err = nullptr, *d_tabs = nullptr;
     LineDev* d_lines = nullptr;
+    double* d_wtab = nullptr;
+    unsigned long long* d_segok = nullptr;
+    double dnu_seg = 0;
     // workspaces (grown on demand)
     double *d_P = nullptr, *d_out = nullptr, *d_partial = nullptr, *d_model = nullptr, *d_bounds = nullptr;
     size_t cap_P = 0, cap_out = 0, cap_partial = 0, cap_model = 0;
@@ -584,7 +681,7 @@ extern "C" const char* mcalf_last_error(const mcalf_ctx* ctx) {
 extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_err, ctx->d_tabs, ctx->d_lines,
+    void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_err, ctx->d_tabs, ctx->d_lines, ctx->d_wtab, ctx->d_segok,
                     ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -639,7 +736,7 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     }
     ctx->ncl_cap = std::max(1, ctx->ncompmax * ctx->nlines + ctx->nfill);
     const size_t fixed_doubles = 2 * (size_t)kLinesPerSync * kTabPad + (size_t)ctx->ncl_cap * kRecStride +
-                                 (2 * (size_t)ctx->n_cap + 8) + 3 * kWaves;
+                                 (2 * (size_t)ctx->n_cap + 8) + 3 * kWaves + 64 * VT_INODES;
     size_t ext = kExtMax;
     while (ext > 0 && (fixed_doubles + tile_doubles((int)ext)) * sizeof(double) > kLdsBudget) ext -= 64;
     if (ext < 2 * (size_t)ctx->n_cap + 64)
@@ -686,6 +783,46 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     HIP_TRY(ctx, hipMemcpy(ctx->d_lines, lines.data(), lines.size() * sizeof(LineDev), hipMemcpyHostToDevice));
     rc = upload_tables(ctx, &ctx->d_tabs);
     if (rc) return rc;
+
+    // Far-wing interpolation set-up: which 64-pixel segments of each tile may be interpolated in
+    // pixel-index space.  A segment qualifies when it lies inside the tile's extent without crossing
+    // the periodic seam and nu(pixel) itself is reproduced by the 8-node interpolant to 1e-15 (true
+    // for linear / logarithmic wavelength grids, false across masked gaps).
+    std::vector<unsigned long long> segok(ctx->ntiles, 0ULL);
+    double dnu_seg = 0.0;
+    for (int t = 0; t < ctx->ntiles; ++t) {
+        const long t0 = (long)t * ctx->tile;
+        const long tlen = std::min<long>(ctx->tile, ctx->npix - t0);
+        const long ext0 = t0 - ctx->n_cap, extCount = tlen + 2L * ctx->n_cap;
+        for (int m = 0; m < 64; ++m) {
+            const long i0 = 64L * m;
+            if (i0 + 64 > extCount) continue;
+            const long e0 = ext0 + i0;
+            if (e0 < 0 || e0 + 63 >= ctx->npix) continue;
+            bool ok = true;
+            const double dir = nu[e0 + 63] - nu[e0];
+            for (int i = 0; i < 64 && ok; ++i) {
+                double v = 0.0;
+                for (int k = 0; k < VT_INODES; ++k) v += VT_INTERP_W_HOST[i * VT_INODES + k] * nu[e0 + VT_INTERP_NODES[k]];
+                const double x = nu[e0 + i];
+                if (!std::isfinite(x) || !(std::fabs(v - x) <= 1e-15 * std::fabs(x))) ok = false;
+                if (i > 0 && !((nu[e0 + i] - nu[e0 + i - 1]) * dir > 0.0)) ok = false;   // strictly monotonic
+            }
+            if (!ok) continue;
+            segok[t] |= 1ULL << m;
+            dnu_seg = std::max(dnu_seg, std::fabs(dir));
+        }
+    }
+    ctx->dnu_seg = dnu_seg;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_segok, segok.size() * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_segok, segok.data(), segok.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_wtab, sizeof(VT_INTERP_W_HOST)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_wtab, VT_INTERP_W_HOST, sizeof(VT_INTERP_W_HOST), hipMemcpyHostToDevice));
+    // more than 64 KiB of dynamic LDS needs the attribute (2 workgroups x 78 KiB fit the 160 KiB of a CU)
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&mcalf_fused_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&mcalf_fused_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     return MCALF_OK;
 }
@@ -746,7 +883,7 @@ static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int
     a.nu = ctx->d_nu; a.obj = ctx->d_obj; a.ispec2 = ctx->d_ispec2; a.lgis = ctx->d_lgis; a.err = ctx->d_err;
     a.asymm = (mode == kModeLogL) ? ctx->asymm : 0; a.veto4 = ctx->veto4; a.veto5 = ctx->veto5;
     a.P = dP; a.partial = ctx->d_partial; a.out = d_out; a.model = d_model;
-    a.lines = ctx->d_lines; a.tabs = ctx->d_tabs;
+    a.lines = ctx->d_lines; a.tabs = ctx->d_tabs; a.wtab = ctx->d_wtab; a.segok = ctx->d_segok; a.dnu_seg = ctx->dnu_seg;
     a.npix = (int)ctx->npix; a.ndim = ctx->ndim; a.ntiles = ctx->ntiles; a.tile = ctx->tile;
     a.n_cap = ctx->n_cap; a.ncl_cap = ctx->ncl_cap;
     a.nlines = ctx->nlines; a.ncompmax = ctx->ncompmax; a.nfill = ctx->nfill;
@@ -884,5 +1021,8 @@ extern "C" int mcalf_voigt_hjerting(const double* x, const double* y, int64_t n,
 #ifdef MCALF_STAMPS
 extern "C" int mcalf_diag_read_stamps(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_stamps), (size_t)n * sizeof(unsigned long long));
+}
+extern "C" int mcalf_diag_read_dbg(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_dbg), 4 * sizeof(unsigned long long));
 }
 #endif

@@ -141,6 +141,24 @@ def build():
     return T, (1 / th, -tc / th)
 
 
+INTERP_NODES = [0, 3, 12, 24, 39, 51, 60, 63]     # near Chebyshev-Lobatto positions in a 64-pixel segment
+
+
+def interp_weights():
+    """W[p][k]: Lagrange basis of node k at in-segment position p (exact rationals -> double)."""
+    W = []
+    for p in range(64):
+        row = []
+        for k, xk in enumerate(INTERP_NODES):
+            num = mp.mpf(1)
+            for m, xm in enumerate(INTERP_NODES):
+                if m != k:
+                    num *= mp.mpf(p - xm) / mp.mpf(xk - xm)
+            row.append(num)
+        W.append(row)
+    return W
+
+
 def main(out_path):
     T, (z1a, z1b) = build()
     L = []
@@ -169,6 +187,14 @@ def main(out_path):
         row = T[n]
         for i in range(0, NTOT, 6):
             L.append("  " + ", ".join(repr(float(v)) for v in row[i:i + 6]) + ",")
+    L.append("};")
+    L.append("// Far-wing interpolation over a 64-pixel segment: 8 nodes (pixel positions) and the Lagrange")
+    L.append("// weights W[p][k] in pixel-index space (DESIGN.md, 'far-wing interpolation').")
+    L.append("#define VT_INODES 8")
+    L.append("static const int VT_INTERP_NODES[8] = {" + ", ".join(str(v) for v in INTERP_NODES) + "};")
+    L.append("static const double VT_INTERP_W_HOST[64 * 8] = {")
+    for row in interp_weights():
+        L.append("  " + ", ".join(repr(float(v)) for v in row) + ",")
     L.append("};")
     with open(out_path, "w") as fh:
         fh.write("\n".join(L) + "\n")

@@ -50,3 +50,19 @@ print("sorted start times [us] every 64th:", ss[::64].round(1).tolist())
 o = np.argsort(start)
 print("blockIdx of first 16 starters:", o[:16].tolist())
 print("lifetimes of first-round (start<3us) mean %.1f, later mean %.1f; n_first=%d" % (life[start < 3].mean(), life[start >= 3].mean(), (start < 3).sum()))
+xcd = np.arange(n) % 8
+print("lifetime by blockIdx%8 (XCD group):", [round(float(life[xcd == k].mean()), 1) for k in range(8)])
+first = start < 3
+print("round-1 lifetime mean %.1f std %.1f; round-2 mean %.1f std %.1f" % (life[first].mean(), life[first].std(), life[~first].mean(), life[~first].std()))
+loop = (st[:, 3] - st[:, 2])
+print("loop cycles by XCD group:", [int(loop[xcd == k].mean()) for k in range(8)])
+print("corr(loop cycles, sum b) = %.3f ; corr(loop, lifetime) = %.3f" % (np.corrcoef(loop, nb)[0, 1], np.corrcoef(loop, life)[0, 1]))
+
+try:
+    dbg = (C.c_ulonglong * 4)()
+    lib.mcalf_diag_read_dbg.argtypes = [C.c_void_p]
+    lib.mcalf_diag_read_dbg(dbg)
+    print("far-wing interpolation: %d of %d (line, segment) pairs interpolated (%.1f %%); segOk bits per 8 = %.2f"
+          % (dbg[0], dbg[1], 100.0 * dbg[0] / max(1, dbg[1]), 8.0 * dbg[2] / max(1, dbg[1])))
+except AttributeError:
+    pass
