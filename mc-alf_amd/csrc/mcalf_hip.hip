@@ -85,12 +85,15 @@ struct KArgs {
     double veto4, veto5;    // asymmetric veto: allowed counts of resid > 4 / > 5 (threshold + grace)
 };
 
-// LDS flux tile: one pad double per 32 entries makes the stride-8 (8 outputs per lane) window
-// reads of the convolution bank-conflict free; row-contiguous accesses stay conflict free.
-__device__ __forceinline__ int tile_pos(int i) { return i + (i >> 5); }
-__host__ __device__ constexpr int tile_doubles(int ext) {
-    const int t = ext + kTileSlack + ((ext + kTileSlack) >> 5) + 1;
-    return t > VT_NY * VT_NTOT ? t : VT_NY * VT_NTOT;      // the region doubles as the T table
+// LDS flux tile, "mod-8 planar": element i lives in plane (i & 7) at index (i >> 3).  The convolution
+// thread that owns outputs 8g..8g+7 then reads every plane at consecutive indices with compile-time
+// offsets (no address arithmetic, lanes hit consecutive slots); the plane stride 516 == 4 (mod 32)
+// also keeps the lane-contiguous flux stores conflict free.
+constexpr int kPlaneStride = (kExtMax + kTileSlack) / 8 + 2;      // 516
+static_assert(kPlaneStride % 32 == 4, "plane stride must be 4 mod 32");
+__device__ __forceinline__ int tile_pos(int i) { return (i & 7) * kPlaneStride + (i >> 3); }
+__host__ __device__ constexpr int tile_doubles(int) {
+    return 8 * kPlaneStride > VT_NY * VT_NTOT ? 8 * kPlaneStride : VT_NY * VT_NTOT;   // the region doubles as the T table
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -168,7 +171,7 @@ __device__ inline void build_line_record(double* rec, double logN, double z, dou
     const float du2 = du * du, du4 = du2 * du2;
     const float q = (float)(kInterpC / kInterpTol) * (float)rec[5] * du4 * du4;
     double uthr = (double)__powf(fmaxf(q, 1.0f), 0.1f) * 1.02;                 // 2 % margin over the float estimate
-    uthr = fmax(uthr, VT_XFAR);
+    uthr = fmax(uthr, sqrt(rec[2]) * 1.0000001);                              // never inside the core table's range
     rec[7] = (flag != 0.0 || !(uthr < 1e30)) ? INFINITY : uthr;               // never interpolate the general path
 }
 
@@ -200,7 +203,7 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
     for (int k = 0; k <= VT_FDEG; ++k) cF[k] = tab[kZFLds + k];
     // Node pass.  Lane l holds node (l & 7) of the wave's segment (l >> 3).  A segment whose eight
     // nodes (both end pixels included, u monotonic along it) all have u >= uthr, or all u <= -uthr,
-    // is far-wing for this line everywhere: its contribution is evaluated at the nodes only and
+    // is wing (|u| >= x_c: no exp(-u^2)) for this line everywhere: its contribution is evaluated at the nodes only and
     // interpolated to the 64 pixels once, after the component loop.  `done` has bit 8 j set when
     // segment j was handled that way.
     unsigned long long done = 0;
@@ -218,10 +221,21 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
         if (done != 0) {                                      // wave-uniform
             const unsigned long long lanes = done * 0xFFULL;  // byte j -> 0xFF: one bit per lane
             const bool mine = (lanes >> (threadIdx.x & 63)) & 1ULL;
-            const double t = fast_rcp(fmax(un * un, kX2Far));
-            double P = cF[VT_FDEG];
+            const double x2n = un * un;
+            const double t = fast_rcp(fmax(x2n, kX2Mid));     // lanes outside `mine` only need to stay finite
+            double P;
+            if (uthr >= VT_XFAR || x2n >= kX2Far) {               // (first test is uniform: strong lines only ever use zone F)
+                P = cF[VT_FDEG];
 #pragma unroll
-            for (int k = VT_FDEG - 1; k >= 0; --k) P = fma(P, t, cF[k]);
+                for (int k = VT_FDEG - 1; k >= 0; --k) P = fma(P, t, cF[k]);
+            } else {
+                const bool z0 = x2n >= kX2Wing;
+                const double sv = z0 ? t : fma(t, VT_Z1_A, VT_Z1_B);
+                const double* cw = tab + (z0 ? kZ0Lds : VT_Z1_OFF);
+                P = cw[VT_WDEG];
+#pragma unroll
+                for (int k = VT_WDEG - 1; k >= 0; --k) P = fma(P, sv, cw[k]);
+            }
             farNode = fma(mine ? t : 0.0, P, farNode);
         }
     }
@@ -482,15 +496,20 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     if (base < tlen) {
         double win[8], top[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) { win[m] = sF[tile_pos(base + m)]; top[m] = 0.0; }
+        const double* fp = sF + tid;                   // element 8 tid + 8 c + r  ->  fp[r * kPlaneStride + c]
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { win[m] = fp[m * kPlaneStride]; top[m] = 0.0; }
+        const double* wp = sW;
         for (int q0 = 0; q0 < ntap8; q0 += 8) {
+            ++fp;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const double w = sW[q0 + r];
+                const double w = wp[r];
 #pragma unroll
                 for (int m = 0; m < 8; ++m) top[m] = fma(win[(m + r) & 7], w, top[m]);
-                win[r] = sF[tile_pos(base + q0 + r + 8)];
+                win[r] = fp[r * kPlaneStride];         // element base + q0 + r + 8
             }
+            wp += 8;
         }
         const double ibot = 1.0 / bot;
 #pragma unroll
