@@ -182,6 +182,12 @@ __device__ unsigned long long g_dbg[4];   // [0] interpolated segments, [1] segm
 #else
 #define MCALF_STAMP(k) do { } while (0)
 #endif
+#ifdef MCALF_STAMPS
+__device__ unsigned long long g_stamps2[8192 * 8];
+#define MCALF_SUB(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps2[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MCALF_SUB(k) do { } while (0)
+#endif
 
 // tau[j] += K H(u_j, y) for the thread's kPpt pixels and one (component,line); `tab` is the line's
 // folded table in LDS, `rec` its record.
@@ -287,6 +293,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     double* sF = sWt + 64 * VT_INODES;                        // tile_doubles(tile + 2 n_cap)
 
     MCALF_STAMP(0);
+    MCALF_SUB(0);
     const int tid = threadIdx.x;
     const int s = blockIdx.x / a.ntiles;
     const int tileIdx = blockIdx.x - s * a.ntiles;
@@ -308,6 +315,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     const int coefPos = tid + (tid >= VT_Z0_OFF ? 1 : 0) + (tid >= VT_ZF_OFF ? 1 : 0);
     const bool coreCoef = tid < VT_NCORE;
 
+    MCALF_SUB(1);
     // ---- 1. decode the parameter vector ---------------------------------------------------
     double R, cont;
     int nc, nfill_eff;
@@ -349,6 +357,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         build_line_record(sRec + cl * kRecStride, logN, z, b, *ln, a.dnu_seg);
     }
 
+    MCALF_SUB(2);
     // ---- LSF taps --------------------------------------------------------------------------
     int n;          // half-width in pixels
     bool bad = false;
@@ -390,6 +399,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         if (idx < VT_NY * VT_NTOT) sT[idx] = treg[i];
     }
 
+    MCALF_SUB(3);
     MCALF_STAMP(1);
     // ---- 2. tau for this thread's pixels ----------------------------------------------------
     // The tile always carries the full provisioned halo n_cap (so that its 64-pixel segments are the
@@ -426,7 +436,9 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         segOk = uniform64(segOk);
     }
 
+    MCALF_SUB(4);
     __syncthreads();                                   // publishes sRec, sW, sT
+    MCALF_SUB(5);
     MCALF_STAMP(2);
     int buf = 0;
 #ifdef MCALF_ABL_NOLOOP   // ablation builds only (tools/); never defined in the product build
@@ -495,7 +507,6 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     const int base = 8 * tid;
     if (base < tlen) {
         double win[8], top[8];
-#pragma unroll
         const double* fp = sF + tid;                   // element 8 tid + 8 c + r  ->  fp[r * kPlaneStride + c]
 #pragma unroll
         for (int m = 0; m < 8; ++m) { win[m] = fp[m * kPlaneStride]; top[m] = 0.0; }
@@ -1040,6 +1051,9 @@ extern "C" int mcalf_voigt_hjerting(const double* x, const double* y, int64_t n,
 #ifdef MCALF_STAMPS
 extern "C" int mcalf_diag_read_stamps(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_stamps), (size_t)n * sizeof(unsigned long long));
+}
+extern "C" int mcalf_diag_read_stamps2(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_stamps2), (size_t)n * sizeof(unsigned long long));
 }
 extern "C" int mcalf_diag_read_dbg(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_dbg), 4 * sizeof(unsigned long long));

@@ -66,3 +66,15 @@ try:
           % (dbg[0], dbg[1], 100.0 * dbg[0] / max(1, dbg[1]), 8.0 * dbg[2] / max(1, dbg[1])))
 except AttributeError:
     pass
+
+try:
+    buf2 = (C.c_ulonglong * (n * 8))()
+    lib.mcalf_diag_read_stamps2.argtypes = [C.c_void_p, C.c_int]
+    lib.mcalf_diag_read_stamps2(buf2, n * 8)
+    s2 = np.array(buf2, dtype=np.uint64).reshape(n, 8).astype(np.int64)
+    nm = ["", "T/weight loads issued", "decode + records", "taps + T store", "nu loads issued", "barrier wait"]
+    for k in range(1, 6):
+        d = s2[:, k] - s2[:, k - 1]
+        print("setup: %-24s mean %7.0f  round1 %7.0f  round2 %7.0f cycles" % (nm[k], d.mean(), d[first].mean(), d[~first].mean()))
+except AttributeError:
+    pass
