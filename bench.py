@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--config", default="B", choices=["A", "B", "C", "E"])
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 = skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the real multi-GPU path) or gloo: a rehearsal of the N>1 control flow on a "
+                         "one-GPU box (all ranks share cuda:0, logL shards gathered through host memory)")
     ap.add_argument("--host-api", action="store_true",
                     help="diagnostic: time the host-pointer entry (H2D of P and D2H of logL inside the step); "
                          "never the headline value")
@@ -78,11 +81,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    rehearsal = world > 1 and args.backend == "gloo"
+    if rehearsal:
+        local_rank = 0                                   # every rank on the one GPU of the box
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     kw, batch, seed = workloads.config(args.config, hip_synth)
     if args.batch:
@@ -97,27 +106,34 @@ def main():
     line_pix = float((nc * nlines + fit.nfill).sum()) * npix
 
     dP = torch.from_numpy(P_host).to(dev)
-    plan = mdist.LogLGather(batch * world, dev)          # rows [rank*batch, (rank+1)*batch) are local
+    # two logL buffers in flight: the (latency-bound) gather of step k overlaps the kernel of step k+1
+    plan = mdist.LogLGather(batch * world, "cpu" if rehearsal else dev, depth=2)
     assert (plan.lo, plan.hi) == (rank * batch, (rank + 1) * batch)
-    dlogL = plan.local
+    dlogL = torch.empty(batch, dtype=torch.float64, device=dev) if (rehearsal or world == 1) else None
     _lib.check(fit._lib.mcalf_reserve(fit._ctx, batch), fit._ctx)
     stream = torch.cuda.current_stream()
     st = C.c_void_p(stream.cuda_stream)
     launch = fit._lib.mcalf_loglike_batch_device
-    ctx, pP, pL = fit._ctx, dP.data_ptr(), dlogL.data_ptr()
+    ctx, pP = fit._ctx, dP.data_ptr()
+    last_out = [dlogL]
 
     def step():
         if args.host_api:
             fit.loglike_batch(P_host)
             return
-        rc = launch(ctx, pP, batch, pL, st)
+        out = dlogL if dlogL is not None else plan.local          # plan.local waits for the slot's old gather
+        rc = launch(ctx, pP, batch, out.data_ptr(), st)
         if rc:
             _lib.check(rc, ctx)
+        last_out[0] = out
         if world > 1:
-            plan.gather()                                # RCCL gather of the logL shards to rank 0
+            if rehearsal:
+                plan.local.copy_(dlogL)                  # through host memory (gloo)
+            plan.gather_async()                          # RCCL gather of the logL shards to rank 0
 
     def fence():
         if world > 1:
+            plan.finish()                                # every outstanding gather has landed on rank 0
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -132,8 +148,9 @@ def main():
     ev1.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([comp_pix, line_pix], dtype=torch.float64, device=dev)
+    red_dev = "cpu" if rehearsal else dev
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([comp_pix, line_pix], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -143,7 +160,7 @@ def main():
     # dominant kernel: average launch duration from HIP events on the launch stream (N=1: the
     # stream carries nothing but the fused kernel; N>1: the gather is on RCCL's own stream)
     kern_ms = ev0.elapsed_time(ev1) / args.steps
-    logL_dev = dlogL.cpu().numpy()
+    logL_dev = last_out[0].cpu().numpy()
 
     out = None
     if rank == 0:
@@ -171,7 +188,8 @@ def main():
                        else "BASELINE config E: HI 1215 damped", "batch_per_gpu": batch, "global_batch": batch * world,
                        "npix": npix, "ncomp": list(kw["ncomp"]), "nlines": nlines, "nfill": fit.nfill, "ndim": ndim,
                        "specres": list(kw["specres"]), "lsf_taps": 2 * n_half + 1, "tiles_per_sample": fit.info.ntiles,
-                       "parallelism": f"dp{world} rows sharded, RCCL gather of logL to rank 0" if world > 1 else "single GPU"},
+                       "parallelism": (f"dp{world} rows sharded, {'gloo REHEARSAL on one GPU' if rehearsal else 'RCCL'} gather of logL to rank 0"
+                                       if world > 1 else "single GPU")},
             "logL_per_s": batch * world * args.steps / elapsed,
             "line_pixel_evals_per_s": line_pix_job * args.steps / elapsed,
             "kernel_ms": kern_ms,

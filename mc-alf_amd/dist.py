@@ -34,34 +34,76 @@ class LogLGather:
     """Pre-allocated gather of per-rank logL shards to `dst` (one collective per batch).
 
     Shards may be ragged; they are padded to the largest shard so that every rank sends the
-    same number of elements (a requirement of gather on both RCCL and gloo)."""
+    same number of elements (a requirement of gather on both RCCL and gloo).
 
-    def __init__(self, batch: int, device, dst: int = 0, group=None, dtype=torch.float64):
+    `depth` > 1 gives a ring of send/receive buffers so that the gather of batch k (issued with
+    `gather_async`) overlaps the evaluation of batch k+1 into the next buffer: the collective is
+    latency-bound (8 KB per rank at BASELINE config B) and would otherwise serialise with a
+    ~0.1 ms kernel.  `local` always points at the buffer the next evaluation should fill and waits
+    for that buffer's previous collective first."""
+
+    def __init__(self, batch: int, device, dst: int = 0, group=None, dtype=torch.float64, depth: int = 1):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.dst = dst
         self.batch = batch
+        self.depth = max(1, int(depth))
         self.counts = shard_counts(batch, self.world)
         self.lo, self.hi = shard_bounds(batch, self.world, self.rank)
         self.width = max(self.counts) if self.counts else 0
-        self.send = torch.zeros(self.width, dtype=dtype, device=device)
-        self.recv = ([torch.empty(self.width, dtype=dtype, device=device) for _ in range(self.world)]
-                     if self.rank == dst else None)
+        self._send = [torch.zeros(self.width, dtype=dtype, device=device) for _ in range(self.depth)]
+        self._recv = ([[torch.empty(self.width, dtype=dtype, device=device) for _ in range(self.world)]
+                       for _ in range(self.depth)] if self.rank == dst else [None] * self.depth)
+        self._work = [None] * self.depth
+        self._slot = 0
+        self._last = None
+
+    # kept for callers that index the single-buffer form
+    @property
+    def send(self) -> torch.Tensor:
+        return self._send[self._slot]
 
     @property
     def local(self) -> torch.Tensor:
-        """View the local evaluator should write its `hi - lo` logL values into."""
-        return self.send[: self.hi - self.lo]
+        """View the local evaluator should write its `hi - lo` logL values into (current slot)."""
+        w = self._work[self._slot]
+        if w is not None:                      # the slot's previous collective must have consumed it
+            w.wait()
+            self._work[self._slot] = None
+        return self._send[self._slot][: self.hi - self.lo]
 
-    def gather(self) -> Optional[torch.Tensor]:
-        """Run the collective; returns the full [batch] vector on `dst`, None elsewhere."""
+    def _assemble(self, slot) -> Optional[torch.Tensor]:
         if self.world == 1:
-            return self.local
-        dist.gather(self.send, self.recv, dst=self.dst, group=self.group)
+            return self._send[slot][: self.hi - self.lo]
         if self.rank != self.dst:
             return None
-        return torch.cat([buf[:c] for buf, c in zip(self.recv, self.counts)])
+        return torch.cat([buf[:c] for buf, c in zip(self._recv[slot], self.counts)])
+
+    def gather(self) -> Optional[torch.Tensor]:
+        """Blocking form: run the collective on the current slot; full [batch] vector on `dst`."""
+        slot = self._slot
+        if self.world > 1:
+            dist.gather(self._send[slot], self._recv[slot], dst=self.dst, group=self.group)
+        self._slot = (slot + 1) % self.depth
+        return self._assemble(slot)
+
+    def gather_async(self) -> None:
+        """Issue the collective for the current slot and move on to the next slot."""
+        slot = self._slot
+        if self.world > 1:
+            self._work[slot] = dist.gather(self._send[slot], self._recv[slot], dst=self.dst, group=self.group,
+                                           async_op=True)
+        self._last = slot
+        self._slot = (slot + 1) % self.depth
+
+    def finish(self) -> Optional[torch.Tensor]:
+        """Wait for every outstanding collective; returns the most recently gathered vector on `dst`."""
+        for i, w in enumerate(self._work):
+            if w is not None:
+                w.wait()
+                self._work[i] = None
+        return None if self._last is None else self._assemble(self._last)
 
 
 def sharded_loglike(evaluate: Callable[[int, int, torch.Tensor], None], batch: int, device, dst: int = 0,

@@ -42,10 +42,18 @@ def _worker(rank, world, port, batch, q):
         for _ in range(2):
             evaluate(plan.lo, plan.hi, plan.local)
             res.append(plan.gather())
+        # pipelined form: two buffers in flight, gather of batch k overlaps the evaluation of k+1
+        ring = mdist.LogLGather(batch, "cpu", depth=2)
+        for k in range(5):
+            out = ring.local
+            out.copy_(torch.from_numpy(_fake_logl(P[ring.lo:ring.hi]) + k))
+            ring.gather_async()
+        last = ring.finish()
         if rank == 0:
+            assert np.array_equal(last.numpy(), _fake_logl(P) + 4)
             q.put((full.numpy().copy(), res[0].numpy().copy(), res[1].numpy().copy()))
         else:
-            assert full is None and res[0] is None
+            assert full is None and res[0] is None and last is None
     finally:
         dist.destroy_process_group()
 
