@@ -124,8 +124,10 @@ int mcalf_loglike_batch(mcalf_ctx* ctx, const double* P, int64_t batch, double* 
 int mcalf_model_batch(mcalf_ctx* ctx, const double* P, int64_t batch, int32_t targonly, double* flux);
 /* chi2[i] = nansum(ispec2 (obj - model)^2); +inf when the model is identically zero. */
 int mcalf_chi2_batch(mcalf_ctx* ctx, const double* P, int64_t batch, double* chi2);
-/* Single-component spectra: rows of Q are (R, cont, N, z, b); fill != 0 uses the filler line. */
-int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batch, int32_t fill, double* flux);
+/* Single-component spectra: rows of Q are (R, cont, N, z, b).  which = 0: every line of the
+ * component (reconstruct_onecomp); 1: the filler line (reconstruct_onecomp_fill); 2 + k: line k
+ * alone (the per-line model calc_w integrates, hires_fitter.py:483). */
+int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batch, int32_t which, double* flux);
 
 /* Same, device pointers + stream, asynchronous. */
 int mcalf_loglike_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, double* dlogL, void* stream);

@@ -333,6 +333,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         nc = (nct >= 1.0) ? ((nct >= (double)a.ncompmax) ? a.ncompmax : (int)nct) : 0;
         nfill_eff = a.targonly ? 0 : a.nfill;           // :437
     }
+    // onecomp_fill: 0 = every line of the component, 1 = the filler line, 2 + k = line k alone
     const int nl_eff = (a.mode == kModeOneComp && a.onecomp_fill) ? 1 : a.nlines;
     const int ncl = nc * nl_eff + nfill_eff;
 
@@ -341,7 +342,8 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         const LineDev* ln;
         if (a.mode == kModeOneComp) {
             logN = p[2]; z = p[3]; b = p[4];
-            ln = a.onecomp_fill ? (a.lines + a.nlines) : (a.lines + cl);
+            ln = (a.onecomp_fill == 0) ? (a.lines + cl)
+               : (a.onecomp_fill == 1) ? (a.lines + a.nlines) : (a.lines + (a.onecomp_fill - 2));
         } else if (cl < nc * a.nlines) {
             const int c = cl / a.nlines;
             const int l = cl - c * a.nlines;
@@ -990,8 +992,11 @@ extern "C" int mcalf_model_batch(mcalf_ctx* ctx, const double* P, int64_t batch,
     return run_host(ctx, kModeModel, P, batch, ctx ? ctx->ndim : 0, targonly ? 1 : 0, 0, nullptr, flux);
 }
 
-extern "C" int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batch, int32_t fill, double* flux) {
-    return run_host(ctx, kModeOneComp, Q, batch, 5, 0, fill ? 1 : 0, nullptr, flux);
+extern "C" int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batch, int32_t which, double* flux) {
+    if (ctx && (which < 0 || which >= 2 + ctx->nlines))
+        return set_err(ctx, MCALF_ERR_INVALID, "onecomp: `which` must be 0 (all lines), 1 (filler) or 2+k with k < %d",
+                       ctx->nlines);
+    return run_host(ctx, kModeOneComp, Q, batch, 5, 0, which, nullptr, flux);
 }
 
 extern "C" int mcalf_scale_cube_batch(mcalf_ctx* ctx, const double* lo, const double* hi, const double* cube,

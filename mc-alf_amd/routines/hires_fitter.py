@@ -314,11 +314,14 @@ class als_fitter:
                                                out.ctypes.data_as(pd)), self._ctx)
         return out
 
-    def onecomp_batch(self, Q, fill=False):
+    def onecomp_batch(self, Q, fill=False, line=None):
+        """Rows (R, cont, N, z, b) -> single-component spectra.  `fill`: the filler line;
+        `line=k`: line k of the multiplet alone; default: every line of the component."""
         Q = self._rows(Q, 5)
         out = np.empty((Q.shape[0], self.obj_wl.size))
+        which = 1 if fill else (0 if line is None else 2 + int(line))
         pd = C.POINTER(C.c_double)
-        _lib.check(self._lib.mcalf_onecomp_batch(self._ctx, Q.ctypes.data_as(pd), Q.shape[0], int(bool(fill)),
+        _lib.check(self._lib.mcalf_onecomp_batch(self._ctx, Q.ctypes.data_as(pd), Q.shape[0], which,
                                                  out.ctypes.data_as(pd)), self._ctx)
         return out
 
@@ -359,6 +362,46 @@ class als_fitter:
         """hires_fitter.py:394-406."""
         return self.onecomp_batch([specresolution, _scalar(continuum), N, z, b], fill=True)[0]
 
+    def calc_w(self, p, lineid=0):
+        """Rest-frame equivalent width of line `lineid` summed over the ACTIVE components
+        (hires_fitter.py:467-491).  The reference slices `p[3*comp+startind : +3]` (:482), i.e. it
+        forgets the ncomp slot and loops over ncompmax; this follows the parameter layout of
+        reconstruct_spec (:431) instead -- a deliberate deviation from a routine no solver calls."""
+        p = np.asarray(p, dtype=float)
+        cont = (p[1] if self.freespecres else p[0]) if self.freecont else _scalar(self.contval)
+        nc = min(max(int(p[self.startind]), 0), self.ncompmax)
+        if nc == 0:
+            return 0.0
+        comps = p[self.startind + 1: self.startind + 1 + 3 * nc].reshape(nc, 3)            # (N, z, b)
+        Q = np.column_stack([np.zeros(nc), np.full(nc, cont), comps])                      # R = 0: unconvolved
+        absorption = self.onecomp_batch(Q, line=lineid)
+        dlambda = np.diff(self.obj_wl)
+        dlambda = np.insert(dlambda, 0, dlambda[0])
+        w = np.sum((1 - (absorption / cont)) * dlambda, axis=1)
+        return float(np.sum(w / (1 + comps[:, 1])))
+
+    def calc_N(self, p):
+        """Total column density log10(sum 10**N) of the slots with z < 10 (the z cut drops the
+        fillers, which sit at z ~ 24).  hires_fitter.py:493-505 strides from `startind` (:499-500),
+        i.e. it reads (ncomp, b1, b2, ...) as N and (N1, N2, ...) as z and always returns -inf for
+        real columns; this strides from the first N slot, as the layout (:431) implies."""
+        p = np.asarray(p, dtype=float)
+        allN = p[self.startind + 1::3]
+        allz = p[self.startind + 2::3]
+        n = min(allN.size, allz.size)
+        allN, allz = allN[:n], allz[:n]
+        return np.log10(np.sum(10 ** allN[allz < 10]))
+
+    @classmethod
+    def from_config(cls, run_params, **extra):
+        """Construct from the dict `readconfig` returns, exactly as cli.py:73-76 does."""
+        return cls(run_params['specfile'], run_params['wavefit'], run_params['linelist'], run_params['ncomp'],
+                   nfill=run_params['nfill'], specres=run_params['specres'], contval=run_params['contval'],
+                   Nrange=run_params['Nrange'], brange=run_params['brange'], zrange=run_params['zrange'],
+                   Nrangefill=run_params['Nrangefill'], brangefill=run_params['brangefill'],
+                   wrangefill=run_params['wrangefill'], coldef=run_params['coldef'],
+                   Asymmlike=run_params['asymmlike'], **extra)
+
     def get_jax_likelihood(self):
         """hires_fitter.py:521-695 returns a JAX-traceable closure.  JAX is not a dependency
         of this package (and the north-star excludes JAX dispatch); use `conv_mode='jax'`
@@ -369,3 +412,123 @@ class als_fitter:
 
 def _scalar(v):
     return float(np.asarray(v, dtype=float).reshape(-1)[0])
+
+
+# ---------------------------------------------------------------------------------------------
+# Module-level helpers of the reference module (usable without an als_fitter instance)
+# ---------------------------------------------------------------------------------------------
+
+def get_parnames(ncomp, cont=False):
+    """hires_fitter.py:749-759."""
+    names = ['Cont'] if cont else []
+    for i in range(1, ncomp + 1):
+        names += ['N%d' % i, 'z%d' % i, 'b%d' % i]
+    return names
+
+
+def write_equal_weights(path, logl, samples):
+    """Chain file in the layout the CLI writes and `pc_analyzer` reads (cli.py:314-325):
+    columns [weight = 1, -2 logL, parameters...]."""
+    logl = np.asarray(logl, dtype=float).reshape(-1)
+    samples = np.asarray(samples, dtype=float).reshape(logl.size, -1)
+    np.savetxt(path, np.column_stack([np.ones_like(logl), -2.0 * logl, samples]))
+
+
+def pc_analyzer(filesbasename, return_sorted=True):
+    """Read `<base>.stats` (log(Z) line) and `<base>_equal_weights.txt`; optionally sort each
+    sample's active components by redshift and blank the inactive ones (hires_fitter.py:704-747)."""
+    lnz = lnz_err = None
+    with open(filesbasename + '.stats') as fh:
+        for line in fh:
+            if line.startswith('log(Z)'):
+                items = line.split()
+                lnz, lnz_err = float(items[2]), float(items[4])
+    allsamples = np.loadtxt(filesbasename + '_equal_weights.txt', ndmin=2)
+    lhoodsamples = -0.5 * allsamples[:, 1]
+    post = allsamples[:, 2:]
+    if not return_sorted:
+        return lnz, lnz_err, lhoodsamples, post
+    print('Sorting components in redshift')
+    out = post.copy()
+    start = (post.shape[1] - 1) % 3                      # index of the ncomp slot (:728)
+    for row_in, row_out in zip(post, out):
+        nc = int(row_in[start])
+        end = start + 1 + 3 * nc
+        row_in[end:] = 99                                # the reference overwrites its input too (:736)
+        triples = row_in[start + 1:end].reshape(nc, 3)
+        order = np.argsort(triples[:, 1])
+        row_out[start + 1:end] = triples[order].reshape(-1)
+        row_out[end:] = np.nan                           # 99 -> nan (:743)
+    out[out == 99] = np.nan
+    return lnz, lnz_err, lhoodsamples, out
+
+
+_BOOL = {'True': True, 'False': False}
+
+
+def _floats(txt):
+    return np.array(txt.split(','), dtype=float)
+
+
+# (section, option, key, default, converter); converter=None keeps the string
+_CONFIG_TABLE = [
+    ('input', 'coldef', 'coldef', ['Wave', 'Flux', 'Err'], lambda t: [x.strip() for x in t.split(',')]),
+    ('input', 'specres', 'specres', np.array([7.0]), _floats),
+    ('input', 'asymmlike', 'asymmlike', False, lambda t: _BOOL[t]),
+    ('input', 'solver', 'solver', 'polychord', None),
+    ('components', 'ncomp', 'ncomp', np.array((1, 1), dtype=int), lambda t: np.array(t.split(','), dtype=int)),
+    ('components', 'nfill', 'nfill', 0, int),
+    ('components', 'contval', 'contval', np.array([1]), _floats),
+    ('components', 'Nrange', 'Nrange', np.array((11.5, 16)), _floats),
+    ('components', 'brange', 'brange', np.array((1, 30)), _floats),
+    ('components', 'zrange', 'zrange', None, _floats),
+    ('components', 'Nrangefill', 'Nrangefill', np.array((11.5, 16)), _floats),
+    ('components', 'brangefill', 'brangefill', np.array((1, 30)), _floats),
+    ('components', 'wrangefill', 'wrangefill', None, _floats),
+    ('plots', 'nmaxcols', 'nmaxcols', 5, lambda t: int(t[0])),        # first character only (:886)
+    ('plots', 'yrange', 'yrange', np.array((-0.1, 1.2)), _floats),
+    ('run', 'dofit', 'dofit', True, lambda t: _BOOL[t]),
+    ('run', 'doplot', 'doplot', True, lambda t: _BOOL[t]),
+    ('run', 'showprogress', 'showprogress', False, lambda t: _BOOL[t]),
+    ('run', 'device', 'device', 'cpu', None),
+]
+
+
+def readconfig(configfile=None, logger=None):
+    """INI file -> run-parameter dict with the keys, defaults and quirks of hires_fitter.py:762-969
+    (mandatory input.specfile / wavefit / linelist; literal 'True'/'False' booleans; chaindir and
+    plotdir prefixed by outdir; solver sections copied verbatim)."""
+    try:
+        import configparser
+    except ImportError:  # pragma: no cover
+        import ConfigParser as configparser
+    cfg = configparser.ConfigParser()
+    cfg.read(configfile)
+    for opt in ('specfile', 'wavefit', 'linelist'):
+        if not cfg.has_option('input', opt):
+            raise configparser.NoOptionError('input', opt)
+    edges = cfg.get('input', 'wavefit').split(',')
+    if len(edges) % 2 == 1:
+        raise ValueError("Number of wavefit values must be even")
+    wavefit = [(float(edges[2 * i]), float(edges[2 * i + 1])) for i in range(len(edges) // 2)]
+
+    def opt(section, name, default, conv=None):
+        if not cfg.has_option(section, name):
+            return default
+        txt = cfg.get(section, name)
+        return txt if conv is None else conv(txt)
+
+    datadir = opt('pathing', 'datadir', './')
+    outdir = opt('pathing', 'outdir', './')
+    run = {'specfile': datadir + cfg.get('input', 'specfile'),
+           'wavefit': wavefit,
+           'linelist': [x.strip() for x in cfg.get('input', 'linelist').split(',')],
+           'chaindir': outdir + opt('pathing', 'chaindir', 'fits/'),
+           'plotdir': outdir + opt('pathing', 'plotdir', 'plots/'),
+           'chainfmt': opt('pathing', 'chainfmt', 'pc_fits_{}_{1}')}
+    for section, name, key, default, conv in _CONFIG_TABLE:
+        run[key] = opt(section, name, default, conv)
+    for section in ('mn_settings', 'pc_settings', 'jaxns_settings'):
+        if cfg.has_section(section):
+            run[section] = {o: _BOOL.get(cfg.get(section, o), cfg.get(section, o)) for o in cfg.options(section)}
+    return run

@@ -338,3 +338,54 @@ def jax_loglike_f64(prob: Problem, p) -> float:
     model = jax_reconstruct_spec_f64(prob, p)
     ispec2 = 1.0 / (prob.err ** 2)
     return float(-0.5 * np.nansum(ispec2 * (prob.flux - model) ** 2 - np.log(ispec2) + np.log(2.0 * np.pi)))
+
+
+# ----------------------------------------------------------------------------------
+# Analysis helpers ("next" rows)
+# ----------------------------------------------------------------------------------
+
+def calc_N_intended(prob: Problem, p) -> float:
+    """hires_fitter.py:493-505 with the stride started at the first N slot (the reference starts
+    at the ncomp slot, :499-500, and therefore always returns -inf for real columns)."""
+    p = np.asarray(p, dtype=float)
+    allN = p[prob.startind + 1::3]
+    allz = p[prob.startind + 2::3]
+    n = min(allN.size, allz.size)
+    ok = allz[:n] < 10
+    return float(np.log10(np.sum(10 ** allN[:n][ok])))
+
+
+def calc_w_intended(prob: Problem, p, lineid: int = 0) -> float:
+    """Equivalent width as hires_fitter.py:467-491 evidently intends it: the reference slices
+    p[3*comp+startind : +3] (:482, missing the +1 of the ncomp slot) over ncompmax components;
+    this uses the layout of reconstruct_spec (:431) over the active components."""
+    p = np.asarray(p, dtype=float)
+    cont = (p[1] if prob.freespecres else p[0]) if prob.freecont else float(np.asarray(prob.contval).reshape(-1)[0])
+    wrest, f, gam = prob.lines[lineid]
+    dl = np.diff(prob.wl)
+    dl = np.insert(dl, 0, dl[0])
+    tot = 0.0
+    for c in range(int(p[prob.startind])):
+        N, z, b = p[1 + 3 * c + prob.startind: 1 + 3 * c + 3 + prob.startind]
+        absorption = (np.zeros_like(prob.flux) + cont) * voigt_model(prob.wl, N, b, z, wrest, f, gam)
+        tot += np.sum((1 - (absorption / cont)) * dl) / (1 + z)
+    return float(tot)
+
+
+def pc_sort_components(postsamples: np.ndarray) -> np.ndarray:
+    """The per-sample redshift sort of hires_fitter.py:726-743, loop for loop."""
+    postsamples = np.array(postsamples, dtype=float, copy=True)
+    postsorted = np.copy(postsamples)
+    ncols = len(postsorted[0])
+    startind = (ncols - 1) % 3
+    for ii in range(len(postsamples[:, 0])):
+        thisncomp = int(postsamples[ii, startind])
+        thisendind = startind + 1 + 3 * thisncomp
+        postsamples[ii, thisendind:] = 99
+        postsorted[ii, thisendind:] = 99
+        zsort = np.argsort(postsamples[ii, startind + 2:startind + 1 + 3 * thisncomp:3])
+        for jj in range(len(zsort)):
+            postsorted[ii, 3 * jj + startind + 1:3 * jj + 3 + startind + 1] = \
+                postsamples[ii, 3 * zsort[jj] + np.array([0, 1, 2]) + startind + 1]
+        postsorted[postsorted == 99] = np.nan
+    return postsorted

@@ -241,3 +241,21 @@ def test_asymmetric_likelihood_veto():
         q = np.array([2.0, 14.5, 3.005, 40.0, 14.5, 3.006, 40.0])   # strong absorption where the data has none
         assert fit.lnlhood_dy(q) == -np.inf
         assert o.lnlhood_worker(prob, q, asymm_thresholds=(0, 0)) == -np.inf
+
+
+def test_single_line_models_and_equivalent_width(cfgC):
+    """mcalf_onecomp_batch(which = 2 + k) and the derived quantities built on it."""
+    kw, _, seed = cfgC
+    prob = problem_from_kwargs(kw)
+    P = workloads.draw_P(kw, 3, np.random.default_rng(seed + 5))
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        for k in range(2):
+            m = fit.onecomp_batch([0.0, 1.0, 13.7, 3.0005, 18.0], line=k)[0]
+            ref = o.voigt_model(prob.wl, 13.7, 18.0, 3.0005, *prob.lines[k])
+            assert np.abs(m - ref).max() < 2e-11      # u-cancellation noise, both sides
+        with pytest.raises(RuntimeError):
+            fit.onecomp_batch([0.0, 1.0, 13.7, 3.0005, 18.0], line=2)
+        for p in P:
+            for k in range(2):
+                assert abs(fit.calc_w(p, lineid=k) - o.calc_w_intended(prob, p, lineid=k)) < 1e-11
+            assert abs(fit.calc_N(p) - o.calc_N_intended(prob, p)) < 1e-13

@@ -1,0 +1,114 @@
+"""CPU: the host-side helpers the mirror adds beyond the likelihood -- INI reader, chain writer /
+reader with the redshift sort, parameter names, total column -- against hand-checked values and
+the oracle's loop-for-loop restatements."""
+import os
+
+import numpy as np
+import pytest
+
+import mcalf_amd
+from mcalf_amd.routines import hires_fitter as h
+from oracle import numpy_oracle as o
+
+CFG = """
+[input]
+specfile = data/spec.txt
+wavefit = 6180,6220, 6300, 6310
+linelist = CIV 1548, CIV 1550
+coldef = Wave, Flux, Err
+solver = jaxns
+specres = 8.0, 9.0
+asymmlike = False
+
+[pathing]
+datadir = ./in/
+outdir = out/
+chainfmt = pc_fits_{0}
+
+[components]
+ncomp = 8,11
+nfill = 4
+contval  = 1
+Nrange = 12.0,14.5
+brange = 10.0, 40.0
+zrange = 2.99, 3.01
+
+[run]
+dofit = True
+doplot = False
+device = cpu
+
+[jaxns_settings]
+max_samples = 2000
+difficult_model = True
+
+[pc_settings]
+nlive = 150
+do_clustering = False
+
+[plots]
+nmaxcols = 37
+"""
+
+
+def test_readconfig_keys_defaults_and_quirks(tmp_path):
+    f = tmp_path / "fit.cfg"
+    f.write_text(CFG)
+    r = h.readconfig(str(f))
+    assert r["specfile"] == "./in/data/spec.txt"
+    assert r["wavefit"] == [(6180.0, 6220.0), (6300.0, 6310.0)]
+    assert r["linelist"] == ["CIV 1548", "CIV 1550"] and r["coldef"] == ["Wave", "Flux", "Err"]
+    assert r["solver"] == "jaxns" and r["asymmlike"] is False and r["device"] == "cpu"
+    assert np.array_equal(r["specres"], [8.0, 9.0]) and np.array_equal(r["ncomp"], [8, 11]) and r["nfill"] == 4
+    assert np.array_equal(r["contval"], [1.0]) and np.array_equal(r["zrange"], [2.99, 3.01])
+    assert np.array_equal(r["Nrangefill"], [11.5, 16]) and r["wrangefill"] is None
+    assert r["chaindir"] == "out/fits/" and r["plotdir"] == "out/plots/" and r["chainfmt"] == "pc_fits_{0}"
+    assert r["nmaxcols"] == 3                      # only the first character is read (hires_fitter.py:886)
+    assert r["dofit"] is True and r["doplot"] is False and r["showprogress"] is False
+    assert r["jaxns_settings"] == {"max_samples": "2000", "difficult_model": True}
+    assert r["pc_settings"] == {"nlive": "150", "do_clustering": False} and "mn_settings" not in r
+    bad = tmp_path / "bad.cfg"
+    bad.write_text("[input]\nspecfile = a\nlinelist = x\n")
+    with pytest.raises(Exception):
+        h.readconfig(str(bad))
+    odd = tmp_path / "odd.cfg"
+    odd.write_text("[input]\nspecfile = a\nlinelist = x\nwavefit = 1,2,3\n")
+    with pytest.raises(ValueError):
+        h.readconfig(str(odd))
+
+
+def test_chain_roundtrip_and_redshift_sort(tmp_path):
+    rng = np.random.default_rng(3)
+    nmax, nsamp = 4, 25
+    samples = np.empty((nsamp, 1 + 1 + 3 * nmax))                # [cont][ncomp][N,z,b]*4  -> startind = 1
+    samples[:, 0] = rng.uniform(0.9, 1.1, nsamp)
+    samples[:, 1] = rng.integers(0, nmax + 1, nsamp)
+    samples[:, 2:] = rng.uniform(1, 5, (nsamp, 3 * nmax))
+    logl = rng.normal(-100, 5, nsamp)
+    base = str(tmp_path / "chain")
+    h.write_equal_weights(base + "_equal_weights.txt", logl, samples)
+    open(base + ".stats", "w").write("header\nlog(Z)       =   -123.4 +/-   0.25\nmore\n")
+    lnz, lnz_err, lh, post = h.pc_analyzer(base, return_sorted=False)
+    assert (lnz, lnz_err) == (-123.4, 0.25)
+    assert np.allclose(lh, logl, rtol=0, atol=1e-12) and np.allclose(post, samples, rtol=0, atol=1e-12)
+    _, _, _, srt = h.pc_analyzer(base, return_sorted=True)
+    want = o.pc_sort_components(np.loadtxt(base + "_equal_weights.txt", ndmin=2)[:, 2:])
+    assert np.array_equal(np.isnan(srt), np.isnan(want))
+    assert np.array_equal(np.nan_to_num(srt), np.nan_to_num(want))
+    for row in srt:                                           # active redshifts ascending, inactive blanked
+        nc = int(row[1])
+        z = row[3:3 + 3 * nc:3]
+        assert np.all(np.diff(z) >= 0) and np.all(np.isnan(row[2 + 3 * nc:]))
+
+
+def test_parnames_and_total_column(monkeypatch):
+    assert h.get_parnames(2) == ["N1", "z1", "b1", "N2", "z2", "b2"]
+    assert h.get_parnames(1, cont=True) == ["Cont", "N1", "z1", "b1"]
+    monkeypatch.setattr(mcalf_amd.als_fitter, "_open_context", lambda self, dev: None)
+    wl = np.linspace(6180, 6220, 200)
+    f = mcalf_amd.als_fitter(None, [[6180, 6220]], ["CIV 1548", "CIV 1550"], [3, 3], nfill=2,
+                             spectrum=(wl, wl * 0 + 1, wl * 0 + 0.02))
+    prob = o.Problem(wl, wl * 0 + 1, wl * 0 + 0.02, o.CIV_LINES, (3, 3), nfill=2, fitrange=[[6180, 6220]])
+    p = np.array([3.0, 13.0, 3.0, 10.0, 13.5, 3.001, 12.0, 14.0, 3.002, 15.0, 12.0, 23.8, 5.0, 12.5, 23.81, 6.0])
+    assert abs(f.calc_N(p) - o.calc_N_intended(prob, p)) < 1e-14
+    assert abs(f.calc_N(p) - np.log10(10 ** 13.0 + 10 ** 13.5 + 10 ** 14.0)) < 1e-13      # fillers (z ~ 24) excluded
