@@ -763,6 +763,11 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX) {
         ctx->jax_half = (int)std::ceil((float)(kKernelReach * sigma_max));   // :557-559 (float32 ceil)
         ctx->n_cap = ctx->jax_half;
+        if (2L * ctx->jax_half + 1 > ctx->npix)
+            return set_err(ctx, MCALF_ERR_INVALID,
+                           "JAX-path LSF kernel (%d taps) is longer than the spectrum (%ld px): the reference's "
+                           "jnp.convolve(..., 'same') / jnp.where (hires_fitter.py:674-681) cannot broadcast either",
+                           2 * ctx->jax_half + 1, ctx->npix);
     } else {
         ctx->n_cap = (rmax > sp->velstep) ? (int)std::ceil(kKernelReach * sigma_max) : 0;
     }
