@@ -60,3 +60,47 @@ def test_product_package_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def _spec(npix=100, **over):
+    """A valid mcalf_spec (kept alive by the returned tuple)."""
+    wl = np.linspace(6180, 6220, max(npix, 1))
+    one = np.ones_like(wl)
+    err = np.full_like(wl, 0.02)
+    pd = C.POINTER(C.c_double)
+    lines = (_lib.mcalf_line * 1)(_lib.mcalf_line(1548.204, 0.1899, 2.643e8))
+    sp = _lib.mcalf_spec(npix=npix, wl=wl.ctypes.data_as(pd), flux=one.ctypes.data_as(pd), err=err.ctypes.data_as(pd),
+                         velstep=1.0, nlines=1, lines=lines, fill=_lib.mcalf_line(250.0, 0.1899, 2.643e8),
+                         ncompmax=2, nfill=0, freespecres=0, freecont=0, specres_fixed=8.0, specres_max=8.0,
+                         contval_fixed=1.0, conv_mode=0, device=-1, asymmlike=0, asymm_n4=0.0, asymm_n5=0.0)
+    for k, v in over.items():
+        setattr(sp, k, v)
+    return sp, (wl, one, err, lines)
+
+
+@pytest.mark.parametrize("over,needle", [
+    (dict(npix=0), "npix"), (dict(nlines=0), "line"), (dict(ncompmax=-1), "negative"),
+    (dict(velstep=0.0), "velstep"), (dict(conv_mode=7), "conv_mode"), (dict(specres_max=float("nan"), freespecres=1), "specres_max"),
+])
+def test_invalid_specs_are_refused_with_a_message(over, needle):
+    """Argument validation happens before any device is touched, so it is testable without a GPU;
+    errors come back as codes + mcalf_last_error, never as exceptions across the ABI."""
+    lib = _lib.load()
+    sp, keep = _spec(**over)
+    ctx = C.c_void_p()
+    rc = lib.mcalf_create(C.byref(sp), C.byref(ctx))
+    assert rc == -1 and not ctx.value                      # MCALF_ERR_INVALID, no half-built context
+    assert needle in lib.mcalf_last_error(None).decode()
+
+
+def test_null_arguments_do_not_crash():
+    lib = _lib.load()
+    assert lib.mcalf_create(None, None) == -1
+    ctx = C.c_void_p()
+    assert lib.mcalf_create(None, C.byref(ctx)) == -1
+    lib.mcalf_destroy(None)
+    assert lib.mcalf_info(None, None) == -1
+    assert lib.mcalf_loglike_batch(None, None, 4, None) == -1
+    assert lib.mcalf_reserve(None, 4) == -1
+    assert lib.mcalf_voigt_hjerting(None, None, -1, None, -1) == -1
+    assert lib.mcalf_voigt_hjerting(None, None, 0, None, -1) == 0

@@ -34,3 +34,50 @@ def test_device_pointer_entries_match_host_entries():
         side.synchronize()
         assert np.array_equal(out.cpu().numpy(), host)
         assert np.array_equal(dm.cpu().numpy(), hmodel)
+
+
+def test_loglike_replays_inside_a_hip_graph():
+    """After mcalf_reserve the *_device entry allocates nothing and synchronises nothing, so it can be
+    captured into a hipGraph (torch.cuda.CUDAGraph) and replayed with new parameters in place."""
+    kw, _, seed = workloads.config("C", oracle_synth)
+    rng = np.random.default_rng(seed + 9)
+    P1, P2 = workloads.draw_P(kw, 257, rng), workloads.draw_P(kw, 257, rng)
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        eager1, eager2 = fit.loglike_batch(P1), fit.loglike_batch(P2)
+        dP = torch.from_numpy(P1).cuda()
+        out = torch.zeros(257, dtype=torch.float64, device="cuda")
+        _lib.check(fit._lib.mcalf_reserve(fit._ctx, 257), fit._ctx)
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                _lib.check(fit._lib.mcalf_loglike_batch_device(fit._ctx, dP.data_ptr(), 257, out.data_ptr(), st), fit._ctx)
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), eager1)
+        dP.copy_(torch.from_numpy(P2))
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), eager2)
+
+
+def test_context_lifecycle_and_capacity_error():
+    kw, _, seed = workloads.config("A")
+    P = workloads.draw_P(kw, 3, np.random.default_rng(seed))
+    first = None
+    for _ in range(40):                                   # create / destroy must not leak or cross-talk
+        with mcalf_amd.als_fitter(None, **kw) as fit:
+            v = fit.loglike_batch(P)
+        first = v if first is None else first
+        assert np.array_equal(v, first)
+    a = mcalf_amd.als_fitter(None, **kw)
+    b = mcalf_amd.als_fitter(None, **dict(kw, specres=[20.0]))
+    assert not np.array_equal(a.loglike_batch(P), b.loglike_batch(P))    # independent contexts
+    a.close(); a.close(); b.close()
+    # an LSF that cannot fit a workgroup tile is refused at creation (MCALF_ERR_RANGE), not mis-computed
+    wl = 6200.0 * np.exp(np.arange(12000) * 0.01 / 2.9979245e5)
+    with pytest.raises(RuntimeError, match="MCALF_ERR_RANGE"):
+        mcalf_amd.als_fitter(None, [[wl[0] - 1, wl[-1] + 1]], ["CIV 1548"], [1, 1], specres=[60.0],
+                             spectrum=(wl, np.ones_like(wl), np.full_like(wl, 0.02)), velstep=0.01)
