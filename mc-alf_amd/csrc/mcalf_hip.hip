@@ -507,7 +507,20 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     // and one (broadcast) weight are read from LDS for eight FMAs.
     double acc = 0.0, nnz = 0.0, c4 = 0.0, c5 = 0.0;
     const int base = 8 * tid;
+    const bool reduces = (a.mode == kModeLogL || a.mode == kModeChi2);
     if (base < tlen) {
+        // The data of this thread's 8 pixels are requested now and consumed after the convolution (the
+        // device arrays carry 8 doubles of padding, so the 64-byte reads never need a bounds test).
+        double ob[8], is2[8], lg[8], er[8];
+        if (reduces) {
+            const size_t o0 = (size_t)(t0 + base);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { ob[m] = a.obj[o0 + m]; is2[m] = a.ispec2[o0 + m]; lg[m] = a.lgis[o0 + m]; }
+            if (a.asymm) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) er[m] = a.err[o0 + m];
+            }
+        }
         double win[8], top[8];
         const double* fp = sF + tid;                   // element 8 tid + 8 c + r  ->  fp[r * kPlaneStride + c]
 #pragma unroll
@@ -528,24 +541,23 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int i = base + m;
-            if (i < tlen) {
-                const int pix = t0 + i;
-                double mval = kZeroPad ? top[m] : top[m] * ibot;
-                if (kZeroPad && (pix < n || pix >= a.npix - n)) mval = sF[tile_pos(i + n)];   // :677-681 edge reset
-                mval *= cont;                                                                  // :447 / :683
-                if (bad) mval = NAN;
-                if (a.model) a.model[(size_t)s * a.npix + pix] = mval;
-                if (a.mode == kModeLogL || a.mode == kModeChi2) {
-                    const double d = a.obj[pix] - mval;
-                    double term = a.ispec2[pix] * (d * d);
-                    if (a.mode == kModeLogL) term = (term - a.lgis[pix]) + a.log2pi;  // :294
-                    if (!isnan(term)) acc += term;                                     // np.nansum
-                    if (mval != 0.0) nnz += 1.0;
-                    if (a.asymm) {                                                     // :298-302
-                        const double resid = d / a.err[pix];
-                        if (resid > 4.0) c4 += 1.0;
-                        if (resid > 5.0) c5 += 1.0;
-                    }
+            const bool live = i < tlen;
+            const int pix = t0 + i;
+            double mval = kZeroPad ? top[m] : top[m] * ibot;
+            if (kZeroPad && (pix < n || pix >= a.npix - n)) mval = sF[tile_pos(min(i, tlen - 1) + n)];   // :677-681 edge reset
+            mval *= cont;                                                                  // :447 / :683
+            if (bad) mval = NAN;
+            if (a.model && live) a.model[(size_t)s * a.npix + pix] = mval;
+            if (reduces) {
+                const double d = ob[m] - mval;
+                double term = is2[m] * (d * d);
+                if (a.mode == kModeLogL) term = (term - lg[m]) + a.log2pi;                 // :294
+                if (live && !isnan(term)) acc += term;                                     // np.nansum
+                if (live && mval != 0.0) nnz += 1.0;
+                if (a.asymm) {                                                             // :298-302
+                    const double resid = d / er[m];
+                    if (live && resid > 4.0) c4 += 1.0;
+                    if (live && resid > 5.0) c5 += 1.0;
                 }
             }
         }
@@ -781,10 +793,12 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
                        "LSF half-width %d px (specres_max %.3g km/s at %.3g km/s/px) with %d component-lines does not "
                        "fit a %d-pixel workgroup tile / the %zu-byte LDS budget", ctx->n_cap, rmax, sp->velstep,
                        ctx->ncl_cap, kExtMax, kLdsBudget);
-    long tile = (long)ext - 2 * ctx->n_cap;
-    if (tile > ctx->npix) tile = ctx->npix;
+    // tiles are multiples of 8 pixels (the epilogue works in aligned groups of 8), balanced over the spectrum
+    const long tmax = ((long)ext - 2 * ctx->n_cap) & ~7L;
+    long tile = std::min(tmax, (ctx->npix + 7) & ~7L);
     long ntiles = (ctx->npix + tile - 1) / tile;
-    tile = (ctx->npix + ntiles - 1) / ntiles;      // balance
+    tile = (((ctx->npix + ntiles - 1) / ntiles) + 7) & ~7L;
+    ntiles = (ctx->npix + tile - 1) / tile;
     ctx->tile = (int)tile;
     ctx->ntiles = (int)ntiles;
     ctx->lds_bytes = (fixed_doubles + (size_t)tile_doubles((int)tile + 2 * ctx->n_cap)) * sizeof(double);
@@ -806,11 +820,16 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         lines[l].nujk = kCcgs / lines[l].wrest_cm;         // :359
     }
     const size_t nb = (size_t)ctx->npix * sizeof(double);
+    const size_t nbp = nb + 8 * sizeof(double);          // the epilogue reads 8 pixels per thread without a bounds test
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_nu, nb));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_obj, nb));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ispec2, nb));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_lgis, nb));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_err, nb));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_obj, nbp));
+    HIP_TRY(ctx, hipMemset(ctx->d_obj, 0, nbp));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ispec2, nbp));
+    HIP_TRY(ctx, hipMemset(ctx->d_ispec2, 0, nbp));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_lgis, nbp));
+    HIP_TRY(ctx, hipMemset(ctx->d_lgis, 0, nbp));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_err, nbp));
+    HIP_TRY(ctx, hipMemset(ctx->d_err, 0, nbp));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_lines, lines.size() * sizeof(LineDev)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_nu, nu.data(), nb, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_obj, sp->flux, nb, hipMemcpyHostToDevice));

@@ -24,7 +24,7 @@ fit = mcalf_amd.als_fitter(None, **kw)
 for _ in range(3):
     fit.loglike_batch(P)
 lib = _lib.load()
-n = batch * fit.info.ntiles
+n = min(batch * fit.info.ntiles, 8192)          # the diagnostic build records the first 8192 workgroups
 buf = (C.c_ulonglong * (n * 8))()
 lib.mcalf_diag_read_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.mcalf_diag_read_stamps(buf, n * 8) == 0
@@ -43,8 +43,7 @@ print("kernel span %.1f us; WG lifetime mean %.1f us (min %.1f, max %.1f); sum(l
       % (end.max(), life.mean(), life.min(), life.max(), life.sum() / 512))
 print("start time percentiles [us]:", np.percentile(start, [0, 25, 50, 75, 100]).round(1).tolist())
 print("end   time percentiles [us]:", np.percentile(end, [0, 25, 50, 75, 90, 99, 100]).round(1).tolist())
-nb = P[:, 3::3][:, :8].sum(axis=1)
-print("corr(lifetime, sum b) = %.3f" % np.corrcoef(life, nb)[0, 1])
+nb = np.resize(P[:, 3::3][:, :8].sum(axis=1), n)
 ss = np.sort(start)
 print("sorted start times [us] every 64th:", ss[::64].round(1).tolist())
 o = np.argsort(start)
@@ -52,11 +51,11 @@ print("blockIdx of first 16 starters:", o[:16].tolist())
 print("lifetimes of first-round (start<3us) mean %.1f, later mean %.1f; n_first=%d" % (life[start < 3].mean(), life[start >= 3].mean(), (start < 3).sum()))
 xcd = np.arange(n) % 8
 print("lifetime by blockIdx%8 (XCD group):", [round(float(life[xcd == k].mean()), 1) for k in range(8)])
-first = start < 3
+first = start < 3 if (start < 3).any() and (start >= 3).any() else (np.arange(n) < n // 2)
 print("round-1 lifetime mean %.1f std %.1f; round-2 mean %.1f std %.1f" % (life[first].mean(), life[first].std(), life[~first].mean(), life[~first].std()))
 loop = (st[:, 3] - st[:, 2])
 print("loop cycles by XCD group:", [int(loop[xcd == k].mean()) for k in range(8)])
-print("corr(loop cycles, sum b) = %.3f ; corr(loop, lifetime) = %.3f" % (np.corrcoef(loop, nb)[0, 1], np.corrcoef(loop, life)[0, 1]))
+
 
 try:
     dbg = (C.c_ulonglong * 4)()
