@@ -315,102 +315,12 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     const int coefPos = tid + (tid >= VT_Z0_OFF ? 1 : 0) + (tid >= VT_ZF_OFF ? 1 : 0);
     const bool coreCoef = tid < VT_NCORE;
 
-    MCALF_SUB(1);
-    // ---- 1. decode the parameter vector ---------------------------------------------------
-    double R, cont;
-    int nc, nfill_eff;
-    if (a.mode == kModeOneComp) {                       // hires_fitter.py:379-406
-        R = p[0];
-        cont = p[1];
-        nc = 1;
-        nfill_eff = 0;
-    } else {
-        R = a.freespecres ? p[0] : a.specres_fixed;     // :412-417
-        cont = a.freecont ? (a.freespecres ? p[1] : p[0]) : a.contval_fixed;   // :419-425
-        const double ncv = p[a.startind];
-        // numpy path: int() truncates (:428); JAX path: floor (:616)
-        const double nct = kZeroPad ? floor(ncv) : trunc(ncv);
-        nc = (nct >= 1.0) ? ((nct >= (double)a.ncompmax) ? a.ncompmax : (int)nct) : 0;
-        nfill_eff = a.targonly ? 0 : a.nfill;           // :437
-    }
-    // onecomp_fill: 0 = every line of the component, 1 = the filler line, 2 + k = line k alone
-    const int nl_eff = (a.mode == kModeOneComp && a.onecomp_fill) ? 1 : a.nlines;
-    const int ncl = nc * nl_eff + nfill_eff;
-
-    for (int cl = tid; cl < ncl; cl += kBlock) {
-        double logN, z, b;
-        const LineDev* ln;
-        if (a.mode == kModeOneComp) {
-            logN = p[2]; z = p[3]; b = p[4];
-            ln = (a.onecomp_fill == 0) ? (a.lines + cl)
-               : (a.onecomp_fill == 1) ? (a.lines + a.nlines) : (a.lines + (a.onecomp_fill - 2));
-        } else if (cl < nc * a.nlines) {
-            const int c = cl / a.nlines;
-            const int l = cl - c * a.nlines;
-            const double* q = p + 1 + 3 * c + a.startind;       // :431  (N, z, b)
-            logN = q[0]; z = q[1]; b = q[2];
-            ln = a.lines + l;
-        } else {
-            const int k = cl - nc * a.nlines;
-            const double* q = p + 3 * k + a.endind;             // :439
-            logN = q[0]; z = q[1]; b = q[2];
-            ln = a.lines + a.nlines;
-        }
-        build_line_record(sRec + cl * kRecStride, logN, z, b, *ln, a.dnu_seg);
-    }
-
-    MCALF_SUB(2);
-    // ---- LSF taps --------------------------------------------------------------------------
-    int n;          // half-width in pixels
-    bool bad = false;
-    const double sigma = (R / kFwhmToSigma) / a.velstep;        // :454 / :667
-    if (kZeroPad) {
-        n = a.jax_half;                                         // :549-560 fixed grid
-    } else if (R > a.velstep) {                                 // :445
-        const double nd = ceil(kKernelReach * sigma);           // :458
-        if (!(nd <= (double)a.n_cap)) { bad = true; n = 0; }
-        else n = (int)nd;                                       // x_size = int(2n)+1  (:459)
-    } else {
-        n = 0;
-    }
-    // Every wave computes the (few) taps itself, so the normalisation needs no workgroup barrier;
-    // wave 0 writes them.  astropy normalises the kernel by its sum and its C loop then divides by
-    // the tap sum it accumulates next to the data sum (`bot`); the JAX path only normalises (:670).
-    const int lane = tid & 63;
-    const int ntap8 = (2 * n + 1 + 7) & ~7;
-    const double inv2s2 = kZeroPad ? 1.0 / (2.0 * sigma * sigma) : 0.5 / (sigma * sigma);
-    const double amp = kZeroPad ? 1.0 : 1.0 / (sqrt(2.0 * M_PI) * sigma);          // Gaussian1DKernel amplitude
-    double gsum = 0.0;
-    for (int k = lane; k <= 2 * n; k += 64) {
-        const double dk = (double)(k - n);
-        gsum += (n == 0 && !kZeroPad) ? 1.0 : exp(-(dk * dk) * inv2s2) * amp;        // :669 / Gaussian1D
-    }
-    gsum = wave_allsum(gsum);
-    double wsum = 0.0;
-    for (int k = lane; k < ntap8; k += 64) {
-        const double dk = (double)(k - n);
-        const double g = (n == 0 && !kZeroPad) ? 1.0 : exp(-(dk * dk) * inv2s2) * amp;
-        const double w = (k <= 2 * n) ? g / gsum : 0.0;                              // zero-padded to 8
-        wsum += w;
-        if (tid < 64) sW[k] = w;
-    }
-    const double bot = kZeroPad ? 1.0 : wave_allsum(wsum);
-#pragma unroll
-    for (int i = 0; i < kTRegs; ++i) {
-        const int idx = tid + i * kBlock;
-        if (idx < VT_NY * VT_NTOT) sT[idx] = treg[i];
-    }
-
-    MCALF_SUB(3);
-    MCALF_STAMP(1);
-    // ---- 2. tau for this thread's pixels ----------------------------------------------------
     // The tile always carries the full provisioned halo n_cap (so that its 64-pixel segments are the
     // same for every sample); a sample with a shorter kernel simply starts `shift` entries in.
     const int t0 = tileIdx * a.tile;
     const int tlen = min(a.tile, a.npix - t0);
     const int ext0 = t0 - a.n_cap;
     const int extCount = tlen + 2 * a.n_cap;
-    const int shift = a.n_cap - n;
     double nu[kPpt], tau[kPpt];
 #pragma unroll
     for (int j = 0; j < kPpt; ++j) {
@@ -439,6 +349,116 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     }
 
     MCALF_SUB(4);
+    MCALF_SUB(1);
+    // ---- 1. decode the parameter vector ---------------------------------------------------
+    double R, cont;
+    int nc, nfill_eff;
+    if (a.mode == kModeOneComp) {                       // hires_fitter.py:379-406
+        R = p[0];
+        cont = p[1];
+        nc = 1;
+        nfill_eff = 0;
+    } else {
+        R = a.freespecres ? p[0] : a.specres_fixed;     // :412-417
+        cont = a.freecont ? (a.freespecres ? p[1] : p[0]) : a.contval_fixed;   // :419-425
+        const double ncv = p[a.startind];
+        // numpy path: int() truncates (:428); JAX path: floor (:616)
+        const double nct = kZeroPad ? floor(ncv) : trunc(ncv);
+        nc = (nct >= 1.0) ? ((nct >= (double)a.ncompmax) ? a.ncompmax : (int)nct) : 0;
+        nfill_eff = a.targonly ? 0 : a.nfill;           // :437
+    }
+    // onecomp_fill: 0 = every line of the component, 1 = the filler line, 2 + k = line k alone
+    const int nl_eff = (a.mode == kModeOneComp && a.onecomp_fill) ? 1 : a.nlines;
+    const int ncl = nc * nl_eff + nfill_eff;
+
+    // One slot per POSSIBLE (component, line) and filler, so that every load below is independent of the
+    // sample's ncomp (one memory round trip); the record lands at its compacted index afterwards.
+    const int nTargetSlots = (a.mode == kModeOneComp) ? nl_eff : a.ncompmax * a.nlines;
+    const int nSlots = nTargetSlots + ((a.mode == kModeOneComp) ? 0 : a.nfill);
+    for (int slot = tid; slot < nSlots; slot += kBlock) {
+        double logN, z, b;
+        const LineDev* ln;
+        int dst;                                    // index in the compacted record list, -1: inactive
+        if (a.mode == kModeOneComp) {
+            logN = p[2]; z = p[3]; b = p[4];
+            ln = (a.onecomp_fill == 0) ? (a.lines + slot)
+               : (a.onecomp_fill == 1) ? (a.lines + a.nlines) : (a.lines + (a.onecomp_fill - 2));
+            dst = slot;
+        } else if (slot < nTargetSlots) {
+            const int c = slot / a.nlines;
+            const int l = slot - c * a.nlines;
+            const double* q = p + 1 + 3 * c + a.startind;       // :431  (N, z, b)
+            logN = q[0]; z = q[1]; b = q[2];
+            ln = a.lines + l;
+            dst = (c < nc) ? slot : -1;                         // components >= int(p[startind]) are skipped (:430)
+        } else {
+            const int k = slot - nTargetSlots;
+            const double* q = p + 3 * k + a.endind;             // :439
+            logN = q[0]; z = q[1]; b = q[2];
+            ln = a.lines + a.nlines;
+            dst = (nfill_eff > 0) ? nc * a.nlines + k : -1;
+        }
+        double rec[kRecStride];
+        build_line_record(rec, logN, z, b, *ln, a.dnu_seg);
+        if (dst >= 0) {
+#pragma unroll
+            for (int k = 0; k < kRecStride; ++k) sRec[dst * kRecStride + k] = rec[k];
+        }
+    }
+
+    MCALF_SUB(2);
+    // ---- LSF taps --------------------------------------------------------------------------
+    int n;          // half-width in pixels
+    bool bad = false;
+    const double sigma = (R / kFwhmToSigma) / a.velstep;        // :454 / :667
+    if (kZeroPad) {
+        n = a.jax_half;                                         // :549-560 fixed grid
+    } else if (R > a.velstep) {                                 // :445
+        const double nd = ceil(kKernelReach * sigma);           // :458
+        if (!(nd <= (double)a.n_cap)) { bad = true; n = 0; }
+        else n = (int)nd;                                       // x_size = int(2n)+1  (:459)
+    } else {
+        n = 0;
+    }
+    // Every wave computes the (few) taps itself, so the normalisation needs no workgroup barrier;
+    // wave 0 writes them.  astropy normalises the kernel by its sum and its C loop then divides by
+    // the tap sum it accumulates next to the data sum (`bot`); the JAX path only normalises (:670).
+    const int lane = tid & 63;
+    const int ntap8 = (2 * n + 1 + 7) & ~7;
+    const double inv2s2 = kZeroPad ? 1.0 / (2.0 * sigma * sigma) : 0.5 / (sigma * sigma);
+    const double amp = kZeroPad ? 1.0 : 1.0 / (sqrt(2.0 * M_PI) * sigma);          // Gaussian1DKernel amplitude
+    double wsum = 0.0;
+    if (ntap8 <= 64) {                               // the usual case: one tap per lane, one exp
+        const double dk = (double)(lane - n);
+        const double g = (lane > 2 * n) ? 0.0 : ((n == 0 && !kZeroPad) ? 1.0 : exp(-(dk * dk) * inv2s2) * amp);
+        const double gsum = wave_allsum(g);
+        wsum = g / gsum;
+        if (tid < ntap8) sW[tid] = wsum;
+    } else {
+        double gsum = 0.0;
+        for (int k = lane; k <= 2 * n; k += 64) {
+            const double dk = (double)(k - n);
+            gsum += exp(-(dk * dk) * inv2s2) * amp;                                  // :669 / Gaussian1D
+        }
+        gsum = wave_allsum(gsum);
+        for (int k = lane; k < ntap8; k += 64) {
+            const double dk = (double)(k - n);
+            const double w = (k <= 2 * n) ? exp(-(dk * dk) * inv2s2) * amp / gsum : 0.0;   // zero-padded to 8
+            wsum += w;
+            if (tid < 64) sW[k] = w;
+        }
+    }
+    const double bot = kZeroPad ? 1.0 : wave_allsum(wsum);
+#pragma unroll
+    for (int i = 0; i < kTRegs; ++i) {
+        const int idx = tid + i * kBlock;
+        if (idx < VT_NY * VT_NTOT) sT[idx] = treg[i];
+    }
+
+    MCALF_SUB(3);
+    MCALF_STAMP(1);
+    // ---- 2. tau for this thread's pixels ----------------------------------------------------
+    const int shift = a.n_cap - n;
     __syncthreads();                                   // publishes sRec, sW, sT
     MCALF_SUB(5);
     MCALF_STAMP(2);
