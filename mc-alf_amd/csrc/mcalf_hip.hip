@@ -63,6 +63,18 @@ struct LineDev {
     double nujk;      // ccgs / wrest_cm           hires_fitter.py:359
 };
 
+// Per-sample set-up, one wave per live point: decode, (component,line) records, LSF taps.  Runs once per
+// sample ahead of the fused kernel (whose workgroups -- several per sample when the spectrum is tiled --
+// then start with plain coalesced loads instead of a chain of dependent loads and libm calls).
+struct SampleHdr {
+    double cont;     // continuum
+    double bot;      // tap sum astropy's loop divides by (1 on the JAX path)
+    int ncl;         // records in use
+    int n;           // LSF half-width of this sample
+    int bad;         // LSF wider than the provisioned halo
+    int pad;
+};
+
 struct KArgs {
     const double* nu;       // [npix] ccgs / (wl/1e8): pixel frequency at z = 0
     const double* obj;      // [npix]
@@ -75,6 +87,9 @@ struct KArgs {
     double* model;          // [batch][npix] or nullptr
     const LineDev* lines;   // [nlines] then the filler line at [nlines]
     const double* tabs;     // T[VT_NY][VT_NTOT]
+    double* recs;           // [batch][ncl_cap][8] records written by the sample kernel
+    double* taps;           // [batch][2 n_cap + 8] normalised LSF taps, zero padded
+    SampleHdr* hdr;         // [batch]
     const double* wtab;     // [64][8] Lagrange weights of the far-wing interpolation
     const unsigned long long* segok;   // [ntiles] bit m: 64-pixel segment m of the tile may be interpolated
     int npix, ndim, ntiles, tile, n_cap, ncl_cap;
@@ -279,6 +294,119 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
     }
 }
 
+template <bool kZeroPad>
+__global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long batch) {
+    const long s = blockIdx.x;
+    if (s >= batch) return;
+    const int lane = threadIdx.x;
+    const int rowlen = (a.mode == kModeOneComp) ? 5 : a.ndim;
+    const double* p = a.P + (size_t)s * rowlen;
+    double* recs = a.recs + (size_t)s * a.ncl_cap * kRecStride;
+    double* taps = a.taps + (size_t)s * (2 * a.n_cap + 8);
+    // ---- 1. decode the parameter vector ---------------------------------------------------
+    double R, cont;
+    int nc, nfill_eff;
+    if (a.mode == kModeOneComp) {                       // hires_fitter.py:379-406
+        R = p[0];
+        cont = p[1];
+        nc = 1;
+        nfill_eff = 0;
+    } else {
+        R = a.freespecres ? p[0] : a.specres_fixed;     // :412-417
+        cont = a.freecont ? (a.freespecres ? p[1] : p[0]) : a.contval_fixed;   // :419-425
+        const double ncv = p[a.startind];
+        // numpy path: int() truncates (:428); JAX path: floor (:616)
+        const double nct = kZeroPad ? floor(ncv) : trunc(ncv);
+        nc = (nct >= 1.0) ? ((nct >= (double)a.ncompmax) ? a.ncompmax : (int)nct) : 0;
+        nfill_eff = a.targonly ? 0 : a.nfill;           // :437
+    }
+    // onecomp_fill: 0 = every line of the component, 1 = the filler line, 2 + k = line k alone
+    const int nl_eff = (a.mode == kModeOneComp && a.onecomp_fill) ? 1 : a.nlines;
+    const int ncl = nc * nl_eff + nfill_eff;
+
+    // One slot per POSSIBLE (component, line) and filler, so that every load below is independent of the
+    // sample's ncomp (one memory round trip); the record lands at its compacted index afterwards.
+    const int nTargetSlots = (a.mode == kModeOneComp) ? nl_eff : a.ncompmax * a.nlines;
+    const int nSlots = nTargetSlots + ((a.mode == kModeOneComp) ? 0 : a.nfill);
+    for (int slot = lane; slot < nSlots; slot += 64) {
+        double logN, z, b;
+        const LineDev* ln;
+        int dst;                                    // index in the compacted record list, -1: inactive
+        if (a.mode == kModeOneComp) {
+            logN = p[2]; z = p[3]; b = p[4];
+            ln = (a.onecomp_fill == 0) ? (a.lines + slot)
+               : (a.onecomp_fill == 1) ? (a.lines + a.nlines) : (a.lines + (a.onecomp_fill - 2));
+            dst = slot;
+        } else if (slot < nTargetSlots) {
+            const int c = slot / a.nlines;
+            const int l = slot - c * a.nlines;
+            const double* q = p + 1 + 3 * c + a.startind;       // :431  (N, z, b)
+            logN = q[0]; z = q[1]; b = q[2];
+            ln = a.lines + l;
+            dst = (c < nc) ? slot : -1;                         // components >= int(p[startind]) are skipped (:430)
+        } else {
+            const int k = slot - nTargetSlots;
+            const double* q = p + 3 * k + a.endind;             // :439
+            logN = q[0]; z = q[1]; b = q[2];
+            ln = a.lines + a.nlines;
+            dst = (nfill_eff > 0) ? nc * a.nlines + k : -1;
+        }
+        double rec[kRecStride];
+        build_line_record(rec, logN, z, b, *ln, a.dnu_seg);
+        if (dst >= 0) {
+#pragma unroll
+            for (int k = 0; k < kRecStride; ++k) recs[dst * kRecStride + k] = rec[k];
+        }
+    }
+
+    // ---- LSF taps --------------------------------------------------------------------------
+    int n;          // half-width in pixels
+    bool bad = false;
+    const double sigma = (R / kFwhmToSigma) / a.velstep;        // :454 / :667
+    if (kZeroPad) {
+        n = a.jax_half;                                         // :549-560 fixed grid
+    } else if (R > a.velstep) {                                 // :445
+        const double nd = ceil(kKernelReach * sigma);           // :458
+        if (!(nd <= (double)a.n_cap)) { bad = true; n = 0; }
+        else n = (int)nd;                                       // x_size = int(2n)+1  (:459)
+    } else {
+        n = 0;
+    }
+    // Every wave computes the (few) taps itself, so the normalisation needs no workgroup barrier;
+    // wave 0 writes them.  astropy normalises the kernel by its sum and its C loop then divides by
+    // the tap sum it accumulates next to the data sum (`bot`); the JAX path only normalises (:670).
+    const int ntap8 = (2 * n + 1 + 7) & ~7;
+    const double inv2s2 = kZeroPad ? 1.0 / (2.0 * sigma * sigma) : 0.5 / (sigma * sigma);
+    const double amp = kZeroPad ? 1.0 : 1.0 / (sqrt(2.0 * M_PI) * sigma);          // Gaussian1DKernel amplitude
+    double wsum = 0.0;
+    if (ntap8 <= 64) {                               // the usual case: one tap per lane, one exp
+        const double dk = (double)(lane - n);
+        const double g = (lane > 2 * n) ? 0.0 : ((n == 0 && !kZeroPad) ? 1.0 : exp(-(dk * dk) * inv2s2) * amp);
+        const double gsum = wave_allsum(g);
+        wsum = g / gsum;
+        if (lane < ntap8) taps[lane] = wsum;
+    } else {
+        double gsum = 0.0;
+        for (int k = lane; k <= 2 * n; k += 64) {
+            const double dk = (double)(k - n);
+            gsum += exp(-(dk * dk) * inv2s2) * amp;                                  // :669 / Gaussian1D
+        }
+        gsum = wave_allsum(gsum);
+        for (int k = lane; k < ntap8; k += 64) {
+            const double dk = (double)(k - n);
+            const double w = (k <= 2 * n) ? exp(-(dk * dk) * inv2s2) * amp / gsum : 0.0;   // zero-padded to 8
+            wsum += w;
+            taps[k] = w;
+        }
+    }
+    const double bot = kZeroPad ? 1.0 : wave_allsum(wsum);
+    if (lane == 0) {
+        SampleHdr h;
+        h.cont = cont; h.bot = bot; h.ncl = ncl; h.n = n; h.bad = bad ? 1 : 0; h.pad = 0;
+        a.hdr[s] = h;
+    }
+}
+
 #ifndef MCALF_MIN_WAVES
 #define MCALF_MIN_WAVES 4
 #endif
@@ -297,9 +425,6 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     const int tid = threadIdx.x;
     const int s = blockIdx.x / a.ntiles;
     const int tileIdx = blockIdx.x - s * a.ntiles;
-    const int rowlen = (a.mode == kModeOneComp) ? 5 : a.ndim;
-    const double* p = a.P + (size_t)s * rowlen;
-
     // The universal table T lives in the LDS region that later holds the flux tile (T is dead once
     // the component loop ends).  Each thread folds ONE coefficient slot per line.
     double* sT = sF;
@@ -348,107 +473,20 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         segOk = uniform64(segOk);
     }
 
-    MCALF_SUB(4);
     MCALF_SUB(1);
-    // ---- 1. decode the parameter vector ---------------------------------------------------
-    double R, cont;
-    int nc, nfill_eff;
-    if (a.mode == kModeOneComp) {                       // hires_fitter.py:379-406
-        R = p[0];
-        cont = p[1];
-        nc = 1;
-        nfill_eff = 0;
-    } else {
-        R = a.freespecres ? p[0] : a.specres_fixed;     // :412-417
-        cont = a.freecont ? (a.freespecres ? p[1] : p[0]) : a.contval_fixed;   // :419-425
-        const double ncv = p[a.startind];
-        // numpy path: int() truncates (:428); JAX path: floor (:616)
-        const double nct = kZeroPad ? floor(ncv) : trunc(ncv);
-        nc = (nct >= 1.0) ? ((nct >= (double)a.ncompmax) ? a.ncompmax : (int)nct) : 0;
-        nfill_eff = a.targonly ? 0 : a.nfill;           // :437
-    }
-    // onecomp_fill: 0 = every line of the component, 1 = the filler line, 2 + k = line k alone
-    const int nl_eff = (a.mode == kModeOneComp && a.onecomp_fill) ? 1 : a.nlines;
-    const int ncl = nc * nl_eff + nfill_eff;
-
-    // One slot per POSSIBLE (component, line) and filler, so that every load below is independent of the
-    // sample's ncomp (one memory round trip); the record lands at its compacted index afterwards.
-    const int nTargetSlots = (a.mode == kModeOneComp) ? nl_eff : a.ncompmax * a.nlines;
-    const int nSlots = nTargetSlots + ((a.mode == kModeOneComp) ? 0 : a.nfill);
-    for (int slot = tid; slot < nSlots; slot += kBlock) {
-        double logN, z, b;
-        const LineDev* ln;
-        int dst;                                    // index in the compacted record list, -1: inactive
-        if (a.mode == kModeOneComp) {
-            logN = p[2]; z = p[3]; b = p[4];
-            ln = (a.onecomp_fill == 0) ? (a.lines + slot)
-               : (a.onecomp_fill == 1) ? (a.lines + a.nlines) : (a.lines + (a.onecomp_fill - 2));
-            dst = slot;
-        } else if (slot < nTargetSlots) {
-            const int c = slot / a.nlines;
-            const int l = slot - c * a.nlines;
-            const double* q = p + 1 + 3 * c + a.startind;       // :431  (N, z, b)
-            logN = q[0]; z = q[1]; b = q[2];
-            ln = a.lines + l;
-            dst = (c < nc) ? slot : -1;                         // components >= int(p[startind]) are skipped (:430)
-        } else {
-            const int k = slot - nTargetSlots;
-            const double* q = p + 3 * k + a.endind;             // :439
-            logN = q[0]; z = q[1]; b = q[2];
-            ln = a.lines + a.nlines;
-            dst = (nfill_eff > 0) ? nc * a.nlines + k : -1;
-        }
-        double rec[kRecStride];
-        build_line_record(rec, logN, z, b, *ln, a.dnu_seg);
-        if (dst >= 0) {
-#pragma unroll
-            for (int k = 0; k < kRecStride; ++k) sRec[dst * kRecStride + k] = rec[k];
-        }
-    }
-
-    MCALF_SUB(2);
-    // ---- LSF taps --------------------------------------------------------------------------
-    int n;          // half-width in pixels
-    bool bad = false;
-    const double sigma = (R / kFwhmToSigma) / a.velstep;        // :454 / :667
-    if (kZeroPad) {
-        n = a.jax_half;                                         // :549-560 fixed grid
-    } else if (R > a.velstep) {                                 // :445
-        const double nd = ceil(kKernelReach * sigma);           // :458
-        if (!(nd <= (double)a.n_cap)) { bad = true; n = 0; }
-        else n = (int)nd;                                       // x_size = int(2n)+1  (:459)
-    } else {
-        n = 0;
-    }
-    // Every wave computes the (few) taps itself, so the normalisation needs no workgroup barrier;
-    // wave 0 writes them.  astropy normalises the kernel by its sum and its C loop then divides by
-    // the tap sum it accumulates next to the data sum (`bot`); the JAX path only normalises (:670).
-    const int lane = tid & 63;
+    // ---- 1. per-sample set-up comes from mcalf_sample_kernel: header, records, taps -----------------
+    const SampleHdr hd = a.hdr[s];
+    const double cont = hd.cont, bot = hd.bot;
+    const int ncl = hd.ncl, n = hd.n;
+    const bool bad = hd.bad != 0;
     const int ntap8 = (2 * n + 1 + 7) & ~7;
-    const double inv2s2 = kZeroPad ? 1.0 / (2.0 * sigma * sigma) : 0.5 / (sigma * sigma);
-    const double amp = kZeroPad ? 1.0 : 1.0 / (sqrt(2.0 * M_PI) * sigma);          // Gaussian1DKernel amplitude
-    double wsum = 0.0;
-    if (ntap8 <= 64) {                               // the usual case: one tap per lane, one exp
-        const double dk = (double)(lane - n);
-        const double g = (lane > 2 * n) ? 0.0 : ((n == 0 && !kZeroPad) ? 1.0 : exp(-(dk * dk) * inv2s2) * amp);
-        const double gsum = wave_allsum(g);
-        wsum = g / gsum;
-        if (tid < ntap8) sW[tid] = wsum;
-    } else {
-        double gsum = 0.0;
-        for (int k = lane; k <= 2 * n; k += 64) {
-            const double dk = (double)(k - n);
-            gsum += exp(-(dk * dk) * inv2s2) * amp;                                  // :669 / Gaussian1D
-        }
-        gsum = wave_allsum(gsum);
-        for (int k = lane; k < ntap8; k += 64) {
-            const double dk = (double)(k - n);
-            const double w = (k <= 2 * n) ? exp(-(dk * dk) * inv2s2) * amp / gsum : 0.0;   // zero-padded to 8
-            wsum += w;
-            if (tid < 64) sW[k] = w;
-        }
+    {
+        const double* gr = a.recs + (size_t)s * a.ncl_cap * kRecStride;
+        for (int i = tid; i < ncl * kRecStride; i += kBlock) sRec[i] = gr[i];
+        const double* gt = a.taps + (size_t)s * (2 * a.n_cap + 8);
+        for (int i = tid; i < ntap8; i += kBlock) sW[i] = gt[i];
     }
-    const double bot = kZeroPad ? 1.0 : wave_allsum(wsum);
+    MCALF_SUB(2);
 #pragma unroll
     for (int i = 0; i < kTRegs; ++i) {
         const int idx = tid + i * kBlock;
@@ -588,7 +626,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     acc = wave_sum(acc);
     nnz = wave_sum(nnz);
     const int wave = tid >> 6;
-    if (lane == 0) { sRed[wave] = acc; sRed[kWaves + wave] = nnz; }
+    if ((tid & 63) == 0) { sRed[wave] = acc; sRed[kWaves + wave] = nnz; }
     double t4 = 0.0, t5 = 0.0;
     if (a.asymm) {                                   // rare path: two more workgroup sums
         __syncthreads();
@@ -676,7 +714,9 @@ struct mcalf_ctx {
     double dnu_seg = 0;
     // workspaces (grown on demand)
     double *d_P = nullptr, *d_out = nullptr, *d_partial = nullptr, *d_model = nullptr, *d_bounds = nullptr;
-    size_t cap_P = 0, cap_out = 0, cap_partial = 0, cap_model = 0;
+    double *d_recs = nullptr, *d_taps = nullptr;
+    SampleHdr* d_hdr = nullptr;
+    size_t cap_P = 0, cap_out = 0, cap_partial = 0, cap_model = 0, cap_recs = 0, cap_taps = 0, cap_hdr = 0;
     hipStream_t stream = nullptr;
 };
 
@@ -746,7 +786,7 @@ extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_err, ctx->d_tabs, ctx->d_lines, ctx->d_wtab, ctx->d_segok,
-                    ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds};
+                    ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds, ctx->d_recs, ctx->d_taps, ctx->d_hdr};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -934,6 +974,14 @@ extern "C" int mcalf_info(const mcalf_ctx* ctx, mcalf_info_t* info) {
     return MCALF_OK;
 }
 
+static int grow_sample_ws(mcalf_ctx* ctx, int64_t batch) {
+    int rc;
+    if ((rc = grow(ctx, &ctx->d_recs, &ctx->cap_recs, (size_t)batch * ctx->ncl_cap * kRecStride))) return rc;
+    if ((rc = grow(ctx, &ctx->d_taps, &ctx->cap_taps, (size_t)batch * (2 * (size_t)ctx->n_cap + 8)))) return rc;
+    if ((rc = grow(ctx, &ctx->d_hdr, &ctx->cap_hdr, (size_t)batch))) return rc;
+    return MCALF_OK;
+}
+
 extern "C" int mcalf_reserve(mcalf_ctx* ctx, int64_t batch) {
     if (!ctx || batch < 0) return set_err(ctx, MCALF_ERR_INVALID, "bad arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -941,6 +989,7 @@ extern "C" int mcalf_reserve(mcalf_ctx* ctx, int64_t batch) {
     if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, (size_t)batch * std::max(ctx->ndim, 5)))) return rc;
     if ((rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
     if ((rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4))) return rc;
+    if ((rc = grow_sample_ws(ctx, batch))) return rc;
     return MCALF_OK;
 }
 
@@ -955,7 +1004,12 @@ static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int
         int rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4);
         if (rc) return rc;
     }
+    {
+        int rc = grow_sample_ws(ctx, batch);
+        if (rc) return rc;
+    }
     KArgs a;
+    a.recs = ctx->d_recs; a.taps = ctx->d_taps; a.hdr = ctx->d_hdr;
     a.nu = ctx->d_nu; a.obj = ctx->d_obj; a.ispec2 = ctx->d_ispec2; a.lgis = ctx->d_lgis; a.err = ctx->d_err;
     a.asymm = (mode == kModeLogL) ? ctx->asymm : 0; a.veto4 = ctx->veto4; a.veto5 = ctx->veto5;
     a.P = dP; a.partial = ctx->d_partial; a.out = d_out; a.model = d_model;
@@ -969,6 +1023,11 @@ static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int
     a.specres_fixed = ctx->specres_fixed; a.contval_fixed = ctx->contval_fixed; a.velstep = ctx->velstep;
     a.log2pi = std::log(2.0 * M_PI);
     const dim3 grid((unsigned)(batch * ctx->ntiles)), block(kBlock);
+    if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX)
+        hipLaunchKernelGGL(mcalf_sample_kernel<true>, dim3((unsigned)batch), dim3(64), 0, stream, a, (long)batch);
+    else
+        hipLaunchKernelGGL(mcalf_sample_kernel<false>, dim3((unsigned)batch), dim3(64), 0, stream, a, (long)batch);
+    HIP_TRY(ctx, hipGetLastError());
     if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX)
         hipLaunchKernelGGL(mcalf_fused_kernel<true>, grid, block, ctx->lds_bytes, stream, a);
     else
