@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real multi-GPU path) or gloo: a rehearsal of the N>1 control flow on a "
                          "one-GPU box (all ranks share cuda:0, logL shards gathered through host memory)")
+    ap.add_argument("--no-launch-events", action="store_true",
+                    help="diagnostic: do not bracket each fused launch with HIP events (measures their overhead)")
     ap.add_argument("--host-api", action="store_true",
                     help="diagnostic: time the host-pointer entry (H2D of P and D2H of logL inside the step); "
                          "never the headline value")
@@ -159,7 +161,18 @@ def main():
 
     # dominant kernel: average launch duration from HIP events on the launch stream (N=1: the
     # stream carries nothing but the fused kernel; N>1: the gather is on RCCL's own stream)
-    kern_ms = ev0.elapsed_time(ev1) / args.steps
+    stream_ms = ev0.elapsed_time(ev1) / args.steps        # everything on the launch stream per step
+    # Dominant kernel alone: a second pass of K launches, each bracketed by HIP events on the launch
+    # stream inside the library.  Kept out of the timed region because the brackets themselves cost
+    # ~5 us per step (measured), which would otherwise be charged to `value`.
+    kern_ms, nl = C.c_double(0.0), C.c_int32(0)
+    if not args.host_api and not args.no_launch_events:
+        _lib.check(fit._lib.mcalf_profile_begin(fit._ctx, args.steps), fit._ctx)
+        for _ in range(args.steps):
+            step()
+        fence()
+        _lib.check(fit._lib.mcalf_profile_end(fit._ctx, C.byref(kern_ms), C.byref(nl)), fit._ctx)
+    kern_ms = kern_ms.value if nl.value else stream_ms      # mean duration of mcalf_fused_kernel alone
     logL_dev = last_out[0].cpu().numpy()
 
     out = None
@@ -192,7 +205,7 @@ def main():
                                        if world > 1 else "single GPU")},
             "logL_per_s": batch * world * args.steps / elapsed,
             "line_pixel_evals_per_s": line_pix_job * args.steps / elapsed,
-            "kernel_ms": kern_ms,
+            "kernel_ms": kern_ms, "stream_ms_per_step": stream_ms,
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mcalf_fused_kernel", "algorithmic_bytes_per_launch": alg_bytes,

@@ -134,6 +134,13 @@ int mcalf_loglike_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, 
 int mcalf_model_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, int32_t targonly,
                              double* dflux, void* stream);
 
+/* Measurement aid: between _begin and _end every fused-kernel launch of this context is bracketed by
+ * HIP events on the stream it is launched on (at most max_launches of them); _end waits for them and
+ * returns the mean duration in milliseconds of mcalf_fused_kernel alone (the small per-sample set-up
+ * kernel that precedes it is outside the bracket). */
+int mcalf_profile_begin(mcalf_ctx* ctx, int32_t max_launches);
+int mcalf_profile_end(mcalf_ctx* ctx, double* mean_ms, int32_t* launches);
+
 /* Prior transform: theta = cube * ptp(bounds) + min(bounds) per dimension; when
  * int_ncomp != 0 the ncomp slot is truncated like Python int() (_scale_cube_pc), otherwise
  * left as is (_scale_cube_mn).  lo/hi are [ndim] host arrays; cube/theta [batch][ndim] host. */

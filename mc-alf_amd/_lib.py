@@ -80,6 +80,8 @@ SYMBOLS = {
     "mcalf_onecomp_batch": (C.c_int, [_CTX, _PD, C.c_int64, C.c_int32, _PD]),
     "mcalf_loglike_batch_device": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "mcalf_model_batch_device": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mcalf_profile_begin": (C.c_int, [_CTX, C.c_int32]),
+    "mcalf_profile_end": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mcalf_scale_cube_batch": (C.c_int, [_CTX, _PD, _PD, _PD, C.c_int64, C.c_int32, _PD]),
     "mcalf_voigt_hjerting": (C.c_int, [_PD, _PD, C.c_int64, _PD, C.c_int32]),
 }

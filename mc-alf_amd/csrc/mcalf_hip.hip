@@ -718,6 +718,10 @@ struct mcalf_ctx {
     SampleHdr* d_hdr = nullptr;
     size_t cap_P = 0, cap_out = 0, cap_partial = 0, cap_model = 0, cap_recs = 0, cap_taps = 0, cap_hdr = 0;
     hipStream_t stream = nullptr;
+    // optional per-launch timing of the fused kernel (mcalf_profile_begin / _end)
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    bool profiling = false;
 };
 
 static int set_err(mcalf_ctx* ctx, int code, const char* fmt, ...) {
@@ -789,6 +793,7 @@ extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
                     ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds, ctx->d_recs, ctx->d_taps, ctx->d_hdr};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1028,17 +1033,53 @@ static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int
     else
         hipLaunchKernelGGL(mcalf_sample_kernel<false>, dim3((unsigned)batch), dim3(64), 0, stream, a, (long)batch);
     HIP_TRY(ctx, hipGetLastError());
+    const bool timed = ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used], stream));
     if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX)
         hipLaunchKernelGGL(mcalf_fused_kernel<true>, grid, block, ctx->lds_bytes, stream, a);
     else
         hipLaunchKernelGGL(mcalf_fused_kernel<false>, grid, block, ctx->lds_bytes, stream, a);
     HIP_TRY(ctx, hipGetLastError());
+    if (timed) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], stream));
+        ctx->ev_used += 2;
+    }
     if (reduces && ctx->ntiles > 1) {
         const int fb = 256;
         hipLaunchKernelGGL(mcalf_finalize_kernel, dim3((unsigned)((batch + fb - 1) / fb)), dim3(fb), 0, stream,
                            ctx->d_partial, d_out, (long)batch, ctx->ntiles, mode, a.asymm, a.veto4, a.veto5);
         HIP_TRY(ctx, hipGetLastError());
     }
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_profile_begin(mcalf_ctx* ctx, int32_t max_launches) {
+    if (!ctx || max_launches <= 0) return set_err(ctx, MCALF_ERR_INVALID, "bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    while (ctx->ev.size() < 2 * (size_t)max_launches) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev.push_back(e);
+    }
+    ctx->ev_used = 0;
+    ctx->profiling = true;
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_profile_end(mcalf_ctx* ctx, double* mean_ms, int32_t* launches) {
+    if (!ctx || !mean_ms) return set_err(ctx, MCALF_ERR_INVALID, "bad arguments");
+    ctx->profiling = false;
+    double sum = 0.0;
+    const size_t n = ctx->ev_used / 2;
+    for (size_t i = 0; i < n; ++i) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2 * i + 1]));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
+        sum += ms;
+    }
+    *mean_ms = n ? sum / (double)n : 0.0;
+    if (launches) *launches = (int32_t)n;
+    ctx->ev_used = 0;
     return MCALF_OK;
 }
 
