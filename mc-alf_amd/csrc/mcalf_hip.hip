@@ -111,6 +111,27 @@ __host__ __device__ constexpr int tile_doubles(int) {
     return 8 * kPlaneStride > VT_NY * VT_NTOT ? 8 * kPlaneStride : VT_NY * VT_NTOT;   // the region doubles as the T table
 }
 
+// Value of lane (l - N) within each row of 16 lanes (0 where there is none): one v_mov_b32_dpp per half,
+// no LDS round trip (ds_bpermute, which __shfl_* compiles to, costs an LDS latency per step).
+template <int kCtrl, int kRowMask = 0xF>
+__device__ __forceinline__ double dpp_move(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, kCtrl, kRowMask, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), kCtrl, kRowMask, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+// Sum over the 64 lanes of a wave; the total ends up in lane 63 (DPP row shifts + row broadcasts).
+__device__ __forceinline__ double wave_sum_to_last(double v) {
+    v += dpp_move<0x111>(v);          // row_shr:1
+    v += dpp_move<0x112>(v);          // row_shr:2
+    v += dpp_move<0x114>(v);          // row_shr:4
+    v += dpp_move<0x118>(v);          // row_shr:8   -> lane 15 of every row holds the row sum
+    v += dpp_move<0x142, 0xA>(v);     // row_bcast:15 into rows 1 and 3
+    v += dpp_move<0x143, 0xC>(v);     // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+    return v;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -623,10 +644,10 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     MCALF_STAMP(5);
     if (a.mode == kModeModel || a.mode == kModeOneComp) return;
 
-    acc = wave_sum(acc);
-    nnz = wave_sum(nnz);
+    acc = wave_sum_to_last(acc);
+    nnz = wave_sum_to_last(nnz);
     const int wave = tid >> 6;
-    if ((tid & 63) == 0) { sRed[wave] = acc; sRed[kWaves + wave] = nnz; }
+    if ((tid & 63) == 63) { sRed[wave] = acc; sRed[kWaves + wave] = nnz; }
     double t4 = 0.0, t5 = 0.0;
     if (a.asymm) {                                   // rare path: two more workgroup sums
         __syncthreads();
