@@ -47,6 +47,9 @@ constexpr size_t kLdsBudget = 78 * 1024;   // two workgroups per CU (160 KiB); n
 #define MCALF_FAR_INTERP 1
 #endif
 constexpr bool kFarInterp = MCALF_FAR_INTERP != 0;
+#ifndef MCALF_BALANCE_PRIO
+#define MCALF_BALANCE_PRIO 1      // progress-based wave priority in the component loop (measured -3.5 % at config B)
+#endif
 constexpr double kInterpC = 1.0e-3;        // interpolation error <= kInterpC (du/u0)^8 (measured 4.4e-4, tools/ + DESIGN.md)
 constexpr double kInterpTol = 1.0e-15;     // allowed optical-depth error per (line, pixel) from the interpolation
 constexpr double kCcgs = 2.9979245e10;  // hires_fitter.py:66
@@ -530,6 +533,16 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     // kLinesPerSync lines are folded per workgroup barrier (their tables are double-buffered), which
     // halves the barriers and averages the per-wave core/wing imbalance over more work.
     for (int cl0 = 0; cl0 < ncl_run; cl0 += kLinesPerSync) {
+#if MCALF_BALANCE_PRIO
+        // Wave priority falls as the workgroup progresses, so of the two workgroups sharing a CU the one
+        // that is behind gets the issue slots (they finish together instead of the older one first).
+        switch ((4 * cl0) / ncl_run) {
+            case 0: __builtin_amdgcn_s_setprio(3); break;
+            case 1: __builtin_amdgcn_s_setprio(2); break;
+            case 2: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(0); break;
+        }
+#endif
         double* tabs = sTab + buf * (kLinesPerSync * kTabPad);
         if (hasCoef) {
             double Tn[VT_NY];
@@ -552,6 +565,9 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         }
     }
     MCALF_STAMP(3);
+#if MCALF_BALANCE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // Interpolate the far-wing node sums to the pixels (tau[j] += sum_k W[lane][k] F[segment j][node k]),
     // then flux = exp(-tau) into the LDS tile.  The node sums travel through the (now dead) folded-table
     // region, one 64-entry row per wave; the tile holds only the sample's own halo n (<= n_cap).
