@@ -51,13 +51,15 @@ def cpu_baseline(kw, P, budget_s):
                           Nrangefill=kw.get("Nrangefill", [11.5, 16]), brangefill=kw.get("brangefill", [1, 30]),
                           fitrange=kw["fitrange"])
     oracle.lnlhood_worker(prob, P[0])          # warm
-    vals, t0 = [], time.perf_counter()
-    for row in P:
-        vals.append(oracle.lnlhood_worker(prob, row))
-        if time.perf_counter() - t0 > budget_s:
-            break
+    vals, t0, done = [], time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:   # cycle over the batch until the time budget is spent
+        row = P[done % len(P)]
+        v = oracle.lnlhood_worker(prob, row)
+        if done < len(P):
+            vals.append(v)
+        done += 1
     dt = time.perf_counter() - t0
-    return np.array(vals), dt, prob
+    return np.array(vals), dt, done
 
 
 def main():
@@ -216,12 +218,13 @@ def main():
                               "algorithmic_flops_per_launch": alg_flops},
         }
         if args.cpu_seconds > 0:
-            vals, dt, _ = cpu_baseline(kw, P_host, args.cpu_seconds)
+            vals, dt, done = cpu_baseline(kw, P_host, args.cpu_seconds)
             k = len(vals)
+            evals = sum(float(nc[i % batch]) for i in range(done)) * npix
             out["cpu_baseline"] = {
-                "value": float(nc[:k].sum()) * npix / dt, "unit": "evals/s", "cores": 1, "kind": "port",
-                "sample": f"first {k} of {batch} rows of the same parameter matrix, numpy/scipy float64 oracle "
-                          f"(oracle/numpy_oracle.py), {dt:.1f} s, {dt / k * 1e3:.2f} ms per logL",
+                "value": evals / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+                "sample": f"{done} logL evaluations cycling over the {batch} rows of the same parameter matrix, "
+                          f"numpy/scipy float64 oracle (oracle/numpy_oracle.py), {dt:.1f} s, {dt / done * 1e3:.2f} ms per logL",
                 "host_cpus": os.cpu_count()}
             out["parity"] = {"max_abs_dlogL_vs_oracle": float(np.abs(vals - logL_dev[:k]).max()), "rows": k}
     fit.close()
