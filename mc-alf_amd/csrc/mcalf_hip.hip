@@ -75,7 +75,7 @@ struct SampleHdr {
     int ncl;         // records in use
     int n;           // LSF half-width of this sample
     int bad;         // LSF wider than the provisioned halo
-    int pad;
+    int ngeneral;    // records that need the general Voigt path
 };
 
 struct KArgs {
@@ -228,21 +228,23 @@ __device__ unsigned long long g_stamps2[8192 * 8];
 #define MCALF_SUB(k) do { } while (0)
 #endif
 
+// acc += a * b and acc += a with the accumulator tied to its register: without the tie the compiler
+// gives every update of the thread's 8 running optical depths a fresh register and copies all of them
+// back at the loop back-edge (16 v_mov_b64 per line).
+__device__ __forceinline__ void fmac_inplace(double& acc, double a, double b) {
+    asm("v_fmac_f64 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void add_inplace(double& acc, double a) {
+    asm("v_add_f64 %0, %0, %1" : "+v"(acc) : "v"(a));
+}
+
 // tau[j] += K H(u_j, y) for the thread's kPpt pixels and one (component,line); `tab` is the line's
 // folded table in LDS, `rec` its record.
 __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const double* __restrict__ rec,
                                           const double (&nu)[kPpt], double (&tau)[kPpt], double nuNode,
                                           double& farNode, unsigned long long segOk) {
     const double A = rec[0], B = rec[1], x2c = rec[2];
-    if (rec[6] != 0.0) {                              // general path (uniform over the workgroup)
-        const double y = rec[3], K = rec[4];
-#pragma unroll 1
-        for (int j = 0; j < kPpt; ++j) {
-            const double u = fma(nu[j], A, -B);
-            tau[j] = fma(K, hjert_general(fabs(u), y), tau[j]);
-        }
-        return;
-    }
+    if (rec[6] != 0.0) return;                        // general-path line: handled by eval_general_lines()
     double cF[VT_FDEG + 1];
 #pragma unroll
     for (int k = 0; k <= VT_FDEG; ++k) cF[k] = tab[kZFLds + k];
@@ -281,7 +283,7 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
 #pragma unroll
                 for (int k = VT_WDEG - 1; k >= 0; --k) P = fma(P, sv, cw[k]);
             }
-            farNode = fma(mine ? t : 0.0, P, farNode);
+            fmac_inplace(farNode, mine ? t : 0.0, P);
         }
     }
 #pragma unroll
@@ -294,7 +296,7 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
             double P = cF[VT_FDEG];
 #pragma unroll
             for (int k = VT_FDEG - 1; k >= 0; --k) P = fma(P, t, cF[k]);
-            tau[j] = fma(t, P, tau[j]);
+            fmac_inplace(tau[j], t, P);
         } else if (x2 >= x2c) {                       // exp(-u^2) gone: polynomial in 1/u^2
             const double t = fast_rcp(x2);
             const bool z0 = x2 >= kX2Wing;
@@ -303,7 +305,7 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
             double P = cw[VT_WDEG];
 #pragma unroll
             for (int k = VT_WDEG - 1; k >= 0; --k) P = fma(P, sv, cw[k]);
-            tau[j] = fma(t, P, tau[j]);
+            fmac_inplace(tau[j], t, P);
         } else {                                      // core table (per-lane LDS gather)
             const double x = fabs(u);
             int jx = (int)(x * 4.0);
@@ -313,7 +315,7 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
             double P = cc[VT_CDEG];
 #pragma unroll
             for (int k = VT_CDEG - 1; k >= 0; --k) P = fma(P, sv, cc[k]);
-            tau[j] += P;
+            add_inplace(tau[j], P);
         }
     }
 }
@@ -352,6 +354,7 @@ __global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long ba
     // sample's ncomp (one memory round trip); the record lands at its compacted index afterwards.
     const int nTargetSlots = (a.mode == kModeOneComp) ? nl_eff : a.ncompmax * a.nlines;
     const int nSlots = nTargetSlots + ((a.mode == kModeOneComp) ? 0 : a.nfill);
+    int ngenLane = 0;
     for (int slot = lane; slot < nSlots; slot += 64) {
         double logN, z, b;
         const LineDev* ln;
@@ -377,6 +380,7 @@ __global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long ba
         }
         double rec[kRecStride];
         build_line_record(rec, logN, z, b, *ln, a.dnu_seg);
+        if (dst >= 0 && rec[6] != 0.0) ++ngenLane;
         if (dst >= 0) {
 #pragma unroll
             for (int k = 0; k < kRecStride; ++k) recs[dst * kRecStride + k] = rec[k];
@@ -424,10 +428,28 @@ __global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long ba
         }
     }
     const double bot = kZeroPad ? 1.0 : wave_allsum(wsum);
+    const int ngen = (int)wave_allsum((double)ngenLane);
     if (lane == 0) {
         SampleHdr h;
-        h.cont = cont; h.bot = bot; h.ncl = ncl; h.n = n; h.bad = bad ? 1 : 0; h.pad = 0;
+        h.cont = cont; h.bot = bot; h.ncl = ncl; h.n = n; h.bad = bad ? 1 : 0; h.ngeneral = ngen;
         a.hdr[s] = h;
+    }
+}
+
+// Lines outside the fast path's damping range (flag != 0; none for physical resonance lines).  Kept out
+// of the hot loop: the call to the non-inlined general Voigt routine would otherwise pin the running
+// optical depths in callee-saved registers and cost a register shuffle per line.
+__device__ __forceinline__ void eval_general_lines(const double* __restrict__ sRec, int ncl, const double (&nu)[kPpt],
+                                                double (&tau)[kPpt]) {
+    for (int cl = 0; cl < ncl; ++cl) {
+        const double* rec = sRec + cl * kRecStride;
+        if (rec[6] == 0.0) continue;
+        const double A = rec[0], B = rec[1], y = rec[3], K = rec[4];
+#pragma unroll 1
+        for (int j = 0; j < kPpt; ++j) {
+            const double u = fma(nu[j], A, -B);
+            tau[j] = fma(K, hjert_general(fabs(u), y), tau[j]);
+        }
     }
 }
 
@@ -564,6 +586,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
                 eval_line(tabs + l * kTabPad, sRec + (cl0 + l) * kRecStride, nu, tau, nuNode, farNode, segOk);
         }
     }
+    if (hd.ngeneral > 0 && ncl_run > 0) eval_general_lines(sRec, ncl, nu, tau);
     MCALF_STAMP(3);
 #if MCALF_BALANCE_PRIO
     __builtin_amdgcn_s_setprio(0);
