@@ -177,6 +177,7 @@ __device__ __forceinline__ double finalize_value(int mode, double sum, double nn
 // 10^x as exp(x ln 10) with the product carried in two doubles (about 1 ulp, a fraction of the cost of pow()).
 __device__ __forceinline__ double pow10_fast(double x) {
     constexpr double kLn10Hi = 2.302585092994045901, kLn10Lo = -2.1707562233822494e-16;
+    if (!(fabs(x) <= 300.0)) return pow(10.0, x);        // +-inf, NaN, over/underflow: the library's edge cases (10**-inf = 0)
     const double p = x * kLn10Hi;
     const double e = fma(x, kLn10Hi, -p) + x * kLn10Lo;
     const double r = exp(p);

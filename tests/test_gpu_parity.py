@@ -259,3 +259,43 @@ def test_single_line_models_and_equivalent_width(cfgC):
             for k in range(2):
                 assert abs(fit.calc_w(p, lineid=k) - o.calc_w_intended(prob, p, lineid=k)) < 1e-11
             assert abs(fit.calc_N(p) - o.calc_N_intended(prob, p)) < 1e-13
+
+
+def test_full_size_properties_configs_C_and_E(cfgC):
+    """Size-independent properties at BASELINE.json's full batches (C: 4096 x 47, E: 16384 x 49 on
+    20000 pixels): shards == whole bit for bit, exact continuum scaling, component-order symmetry,
+    a zero-column component is a no-op."""
+    kw, batch, seed = cfgC
+    P = workloads.draw_P(kw, batch, np.random.default_rng(seed))
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        full = fit.loglike_batch(P)
+        assert np.all(np.isfinite(full))
+        parts = np.concatenate([fit.loglike_batch(P[i:i + 512]) for i in range(0, batch, 512)])
+        assert np.array_equal(full, parts)
+        # swap the first two components of every row: same physics, different summation order
+        Q = P.copy()
+        Q[:, 2:5], Q[:, 5:8] = P[:, 5:8], P[:, 2:5]
+        swapped = fit.loglike_batch(Q)
+        assert (np.abs(swapped - full) / np.abs(full)).max() < 1e-12
+    kwc = dict(kw, contval=[0.5, 2.0])                      # free continuum: slot 1
+    Pc = workloads.draw_P(kwc, 64, np.random.default_rng(seed + 1))
+    with mcalf_amd.als_fitter(None, **kwc) as fit:
+        m1 = fit.model_batch(Pc)
+        Pc2 = Pc.copy()
+        Pc2[:, 1] *= 2.0
+        assert np.array_equal(fit.model_batch(Pc2), 2.0 * m1)          # exact power-of-two scaling
+        Pz = Pc.copy()
+        Pz[:, 3] = -np.inf                                              # first component: zero column
+        Pd = Pc.copy()
+        Pd[:, 3] = -400.0                                               # 10**-400 underflows to the same zero
+        assert np.array_equal(fit.model_batch(Pz), fit.model_batch(Pd))
+    kwE, batchE, seedE = workloads.config("E", oracle_synth)
+    PE = workloads.draw_P(kwE, batchE, np.random.default_rng(seedE), damped=2)
+    with mcalf_amd.als_fitter(None, **kwE) as fit:
+        fullE = fit.loglike_batch(PE)
+        assert np.all(np.isfinite(fullE)) and fit.info.ntiles == 5
+        idx = np.random.default_rng(0).choice(batchE, 96, replace=False)
+        assert np.array_equal(fit.loglike_batch(PE[idx]), fullE[idx])
+        m = fit.model_batch(PE[:32])
+        assert np.all(m >= 0.0) and np.all(m <= 1.0 + 1e-12)
+        assert np.any(m == 0.0)                                         # damped cores underflow to exactly 0
