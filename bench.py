@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real multi-GPU path) or gloo: a rehearsal of the N>1 control flow on a "
                          "one-GPU box (all ranks share cuda:0, logL shards gathered through host memory)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="independent batches kept in flight (contexts + streams); 1 = the headline configuration")
     ap.add_argument("--no-launch-events", action="store_true",
                     help="diagnostic: do not bracket each fused launch with HIP events (measures their overhead)")
     ap.add_argument("--host-api", action="store_true",
@@ -117,6 +119,15 @@ def main():
     _lib.check(fit._lib.mcalf_reserve(fit._ctx, batch), fit._ctx)
     stream = torch.cuda.current_stream()
     st = C.c_void_p(stream.cuda_stream)
+    # optional: further independent batches in flight, each with its own context, stream and output
+    extra = []
+    if args.inflight > 1 and world == 1 and not args.host_api:
+        for _ in range(args.inflight - 1):
+            f2 = mcalf_amd.als_fitter(None, device=local_rank, **kw)
+            _lib.check(f2._lib.mcalf_reserve(f2._ctx, batch), f2._ctx)
+            s2 = torch.cuda.Stream()
+            extra.append((f2, s2, torch.empty(batch, dtype=torch.float64, device=dev)))
+    turn = [0]
     launch = fit._lib.mcalf_loglike_batch_device
     ctx, pP = fit._ctx, dP.data_ptr()
     last_out = [dlogL]
@@ -125,6 +136,15 @@ def main():
         if args.host_api:
             fit.loglike_batch(P_host)
             return
+        if extra:
+            k = turn[0] % (len(extra) + 1)
+            turn[0] += 1
+            if k > 0:
+                f2, s2, o2 = extra[k - 1]
+                rc = launch(f2._ctx, pP, batch, o2.data_ptr(), C.c_void_p(s2.cuda_stream))
+                if rc:
+                    _lib.check(rc, f2._ctx)
+                return
         out = dlogL if dlogL is not None else plan.local          # plan.local waits for the slot's old gather
         rc = launch(ctx, pP, batch, out.data_ptr(), st)
         if rc:
@@ -198,7 +218,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic", "entry": "host pointers (PCIe inclusive)" if args.host_api else "device pointers",
+            "dtype": "f64", "data": "synthetic", "batches_in_flight": max(1, args.inflight if (world == 1 and not args.host_api) else 1), "entry": "host pointers (PCIe inclusive)" if args.host_api else "device pointers",
             "config": {"workload": f"BASELINE config {args.config}: CIV 1548/1550 synthetic spectrum" if args.config != "E"
                        else "BASELINE config E: HI 1215 damped", "batch_per_gpu": batch, "global_batch": batch * world,
                        "npix": npix, "ncomp": list(kw["ncomp"]), "nlines": nlines, "nfill": fit.nfill, "ndim": ndim,
