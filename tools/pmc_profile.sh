@@ -23,4 +23,13 @@ with open(out+'/summary.txt','w') as fh:
     for k,(v,n) in sorted(agg.items()):
         line='%-24s per-dispatch mean %.6g  (dispatches %d)'%(k, v/n, n)
         print(line); fh.write(line+'\n')
+# HBM traffic per bench launch for profiles/traffic.json: the fused kernel runs once more than the bench
+# launches (truth synthesis, one workgroup), FETCH_SIZE / WRITE_SIZE are KiB, and gfx950 reports half the
+# bytes of coalesced reads (MI355X_MICROARCH.md) -> read side doubled.
+if 'FETCH_SIZE' in agg and 'WRITE_SIZE' in agg:
+    import json
+    (fv,fn),(wv,wn)=agg['FETCH_SIZE'],agg['WRITE_SIZE']
+    fetch=fv/max(fn-1,1); write=wv/max(wn-1,1)
+    json.dump({"fetch_size_kib_raw":fetch,"write_size_kib":write,"traffic_bytes_per_launch":(2*fetch+write)*1024,
+               "dispatches":fn}, open(out+'/traffic.json','w'), indent=1)
 PY
