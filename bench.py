@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real multi-GPU path) or gloo: a rehearsal of the N>1 control flow on a "
                          "one-GPU box (all ranks share cuda:0, logL shards gathered through host memory)")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="threads of the second CPU baseline (plain-C/OpenMP oracle); 0 = skip it")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent batches kept in flight (contexts + streams); 1 = the headline configuration")
     ap.add_argument("--no-launch-events", action="store_true",
@@ -247,6 +249,27 @@ def main():
                           f"numpy/scipy float64 oracle (oracle/numpy_oracle.py), {dt:.1f} s, {dt / done * 1e3:.2f} ms per logL",
                 "host_cpus": os.cpu_count()}
             out["parity"] = {"max_abs_dlogL_vs_oracle": float(np.abs(vals - logL_dev[:k]).max()), "rows": k}
+            if args.cpu_threads > 0:
+                # second CPU figure: the plain-C/OpenMP restatement (oracle/c), several host threads
+                from oracle import c_oracle, numpy_oracle
+                wl_, flux_, err_ = kw["spectrum"]
+                prob = numpy_oracle.Problem(wl_, flux_, err_, kw["linepars"], tuple(kw["ncomp"]), nfill=kw.get("nfill", 0),
+                                            specres=kw["specres"], Nrange=kw["Nrange"], brange=kw["brange"],
+                                            zrange=kw["zrange"], Nrangefill=kw.get("Nrangefill", [11.5, 16]),
+                                            brangefill=kw.get("brangefill", [1, 30]), fitrange=kw["fitrange"])
+                nthr = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+                co = c_oracle.COracle(prob, threads=nthr)
+                rows = P_host[: min(batch, 64 * nthr)]
+                co.loglike_batch(rows[:nthr])
+                tc, reps = time.perf_counter(), 0
+                while time.perf_counter() - tc < 5.0:
+                    cvals = co.loglike_batch(rows)
+                    reps += 1
+                dtc = time.perf_counter() - tc
+                out["cpu_baseline_c_openmp"] = {
+                    "value": reps * float(nc[: len(rows)].sum()) * npix / dtc, "unit": "evals/s", "cores": nthr, "kind": "port",
+                    "sample": f"{reps} x {len(rows)} rows, oracle/c/mcalf_oracle.c (gcc -O2 -fopenmp), {dtc:.1f} s",
+                    "max_abs_dlogL_vs_gpu": float(np.abs(cvals - logL_dev[: len(rows)]).max())}
     fit.close()
     if world > 1:
         dist.barrier()

@@ -1,0 +1,48 @@
+"""CPU: the plain-C oracle (independent Faddeeva implementation) against the numpy/scipy oracle, the
+reference's fixtures and mpmath."""
+import os
+
+import mpmath as mp
+import numpy as np
+
+from cases import seeded_noise
+from mcalf_amd import workloads
+from oracle import c_oracle
+from oracle import numpy_oracle as o
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_c_faddeeva_against_mpmath():
+    mp.mp.dps = 40
+    d = np.loadtxt(os.path.join(GOLD, "civ_mock_spec.txt"))
+    co = c_oracle.COracle(o.Problem(d[:, 0], d[:, 1], d[:, 2], o.CIV_LINES, (1, 1), specres=[8.0]))
+    rng = np.random.default_rng(2)
+    for a in (1e-9, 1.8e-5, 1.2e-3, 0.02, 1.5):
+        for x in np.concatenate([rng.uniform(0, 8, 25), rng.uniform(8, 60, 10), [0.0, 300.0, 2500.0]]):
+            z = mp.mpf(float(x)) + 1j * mp.mpf(a)
+            ex = float(mp.re(mp.exp(-z * z) * mp.erfc(-1j * z)))
+            assert abs(co.re_w(x, a) - ex) <= 1e-17 + 3e-14 * ex, (x, a)
+
+
+def test_c_oracle_reproduces_the_reference_fixtures():
+    d1 = np.loadtxt(os.path.join(GOLD, "civ_mock_spec.txt"))
+    d2 = np.loadtxt(os.path.join(GOLD, "civ_mock_spec_multicomp.txt"))
+    prob = o.Problem(d1[:, 0], d1[:, 1], d1[:, 2], o.CIV_LINES, (1, 1), specres=[8.0])
+    co = c_oracle.COracle(prob)
+    m1 = co.model_batch(np.array([[1.0, 13.8, 3.0, 15.0]]))[0]
+    assert np.abs(d1[:, 1] - seeded_noise() - m1).max() < 1e-13                       # G1
+    P = np.array([[1.0, workloads.TRUTH_N[i], workloads.TRUTH_Z[i], workloads.TRUTH_B[i]] for i in range(10)])
+    assert np.abs(d2[:, 1] - seeded_noise() - np.prod(co.model_batch(P), axis=0)).max() < 1e-13   # G2
+
+
+def test_c_oracle_matches_numpy_oracle_on_random_draws_and_threads():
+    kw, _, seed = workloads.config("A")
+    wl, flux, err = kw["spectrum"]
+    prob = o.Problem(wl, flux, err, kw["linepars"], (2, 2), specres=[8.0], Nrange=kw["Nrange"], brange=kw["brange"],
+                     zrange=kw["zrange"], fitrange=kw["fitrange"])
+    P = workloads.draw_P(kw, 12, np.random.default_rng(seed))
+    want = o.loglike_batch(prob, P)
+    for threads in (1, 4):
+        got = c_oracle.COracle(prob, threads=threads).loglike_batch(P)
+        assert (np.abs(got - want) / np.abs(want)).max() < 1e-11
