@@ -14,6 +14,7 @@ import pytest
 import mcalf_amd
 from mcalf_amd import workloads
 from cases import oracle_synth, problem_from_kwargs, seeded_noise
+from oracle import c_oracle
 from oracle import numpy_oracle as o
 
 pytestmark = pytest.mark.gpu
@@ -36,6 +37,10 @@ def check_batch(kw, P, n_model=4):
     assert np.abs(got - want).max() < LOGL_ATOL, np.abs(got - want).max()
     # also a relative bar: 1e-10 of |logL| (bad fits have |logL| ~ 1e6)
     assert (np.abs(got - want) / np.maximum(1.0, np.abs(want))).max() < 1e-10
+    # second, independent oracle: plain C with its own Faddeeva routine
+    want_c = c_oracle.COracle(prob, threads=8).loglike_batch(P)
+    assert np.abs(got - want_c).max() < LOGL_ATOL
+    assert (np.abs(got - want_c) / np.maximum(1.0, np.abs(want_c))).max() < 1e-10
     for i in range(n_model):
         ref = o.reconstruct_spec(prob, P[i])
         assert np.abs(models[i] - ref).max() < 1e-11
