@@ -17,6 +17,7 @@
  *   mcalf_onecomp_batch    <- reconstruct_onecomp / _onecomp_fill     hires_fitter.py:379-406
  *   mcalf_chi2_batch       <- als_fitter.chi2                         hires_fitter.py:236-248
  *   mcalf_scale_cube_batch <- _scale_cube_pc / _scale_cube_mn         hires_fitter.py:202-216
+ *   mcalf_loglike_cube_batch <- lnlhood_pc(_scale_cube_pc(cube))      hires_fitter.py:202-209,250-262
  *   mcalf_voigt_hjerting   <- scipy.special.wofz(u + i a).real        hires_fitter.py:365
  *                             / voigt_jax.hjert                       voigt_jax.py:121-127
  *
@@ -146,6 +147,18 @@ int mcalf_profile_end(mcalf_ctx* ctx, double* mean_ms, int32_t* launches);
  * left as is (_scale_cube_mn).  lo/hi are [ndim] host arrays; cube/theta [batch][ndim] host. */
 int mcalf_scale_cube_batch(mcalf_ctx* ctx, const double* lo, const double* hi, const double* cube,
                            int64_t batch, int32_t int_ncomp, double* theta);
+
+/* Unit cube in -> logL out: the composition lnlhood_pc(_scale_cube_pc(cube))
+ * (hires_fitter.py:202-209 + :250-262) without materialising theta on the host.  mcalf_set_prior stores
+ * the box (lo/hi [ndim], host, copied) and whether the ncomp slot is truncated (_scale_cube_pc) or not
+ * (_scale_cube_mn); the prior transform is then applied inside the per-sample set-up kernel with numpy's
+ * rounding (separate multiply and add), so logL is bit-identical to mcalf_loglike_batch on the rows
+ * mcalf_scale_cube_batch returns.  theta / dtheta may be NULL; otherwise they receive the transformed
+ * rows [batch][ndim] (what the sampler stores as the live point). */
+int mcalf_set_prior(mcalf_ctx* ctx, const double* lo, const double* hi, int32_t int_ncomp);
+int mcalf_loglike_cube_batch(mcalf_ctx* ctx, const double* cube, int64_t batch, double* theta, double* logL);
+int mcalf_loglike_cube_batch_device(mcalf_ctx* ctx, const double* dcube, int64_t batch, double* dtheta,
+                                    double* dlogL, void* stream);
 
 /* Diagnostic: out[i] = H(x[i], y[i]) = Re w(x + i y) evaluated by the device Voigt function
  * (host pointers).  device = -1 for the current device. */

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCALF_HIP_LIB") or os.path.join(_HERE, "csrc", "libmcalf_hip.so")
 
 MCALF_OK = 0
+MCALF_ERR_INVALID, MCALF_ERR_HIP, MCALF_ERR_NODEVICE, MCALF_ERR_RANGE, MCALF_ERR_NOMEM = -1, -2, -3, -4, -5
 MCALF_CONV_WRAP_NUMPY = 0
 MCALF_CONV_SAME_EDGE_JAX = 1
 
@@ -83,6 +84,9 @@ SYMBOLS = {
     "mcalf_profile_begin": (C.c_int, [_CTX, C.c_int32]),
     "mcalf_profile_end": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mcalf_scale_cube_batch": (C.c_int, [_CTX, _PD, _PD, _PD, C.c_int64, C.c_int32, _PD]),
+    "mcalf_set_prior": (C.c_int, [_CTX, _PD, _PD, C.c_int32]),
+    "mcalf_loglike_cube_batch": (C.c_int, [_CTX, _PD, C.c_int64, _PD, _PD]),
+    "mcalf_loglike_cube_batch_device": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcalf_voigt_hjerting": (C.c_int, [_PD, _PD, C.c_int64, _PD, C.c_int32]),
 }
 

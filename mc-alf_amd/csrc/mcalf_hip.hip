@@ -101,6 +101,12 @@ struct KArgs {
     double specres_fixed, contval_fixed, velstep, log2pi;
     double dnu_seg;         // largest |nu(first) - nu(last)| over the 64-pixel segments
     double veto4, veto5;    // asymmetric veto: allowed counts of resid > 4 / > 5 (threshold + grace)
+    // unit-cube input (mcalf_loglike_cube_batch*): P holds cube rows and the prior transform of
+    // hires_fitter.py:202-216 is applied while decoding; nullptr = P holds theta
+    const double* prior_lo;
+    const double* prior_hi;
+    double* theta_out;      // [batch][ndim] transformed parameters, or nullptr
+    int prior_int;          // 1: int() on the ncomp slot (_scale_cube_pc), 0: leave (_scale_cube_mn)
 };
 
 // LDS flux tile, "mod-8 planar": element i lives in plane (i & 7) at index (i >> 3).  The convolution
@@ -321,6 +327,22 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
     }
 }
 
+// theta[i] of one sample: either the row element itself or, with unit-cube input, cube*ptp + min with the
+// separately rounded multiply and add numpy performs (hires_fitter.py:206 / :214) and int() on the ncomp slot.
+__device__ __forceinline__ double sample_param(const KArgs& a, const double* __restrict__ p, int i) {
+    double v = p[i];
+    if (a.prior_lo) {
+        const double lo = a.prior_lo[i], hi = a.prior_hi[i];
+        {
+#pragma clang fp contract(off)
+            const double scaled = v * (hi - lo);
+            v = scaled + lo;
+        }
+        if (a.prior_int && i == a.startind) v = trunc(v);        // :207-208
+    }
+    return v;
+}
+
 template <bool kZeroPad>
 __global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long batch) {
     const long s = blockIdx.x;
@@ -339,9 +361,11 @@ __global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long ba
         nc = 1;
         nfill_eff = 0;
     } else {
-        R = a.freespecres ? p[0] : a.specres_fixed;     // :412-417
-        cont = a.freecont ? (a.freespecres ? p[1] : p[0]) : a.contval_fixed;   // :419-425
-        const double ncv = p[a.startind];
+        R = a.freespecres ? sample_param(a, p, 0) : a.specres_fixed;     // :412-417
+        cont = a.freecont ? sample_param(a, p, a.freespecres ? 1 : 0) : a.contval_fixed;   // :419-425
+        const double ncv = sample_param(a, p, a.startind);
+        if (a.theta_out)
+            for (int i = lane; i < a.ndim; i += 64) a.theta_out[(size_t)s * a.ndim + i] = sample_param(a, p, i);
         // numpy path: int() truncates (:428); JAX path: floor (:616)
         const double nct = kZeroPad ? floor(ncv) : trunc(ncv);
         nc = (nct >= 1.0) ? ((nct >= (double)a.ncompmax) ? a.ncompmax : (int)nct) : 0;
@@ -368,14 +392,14 @@ __global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long ba
         } else if (slot < nTargetSlots) {
             const int c = slot / a.nlines;
             const int l = slot - c * a.nlines;
-            const double* q = p + 1 + 3 * c + a.startind;       // :431  (N, z, b)
-            logN = q[0]; z = q[1]; b = q[2];
+            const int q = 1 + 3 * c + a.startind;               // :431  (N, z, b)
+            logN = sample_param(a, p, q); z = sample_param(a, p, q + 1); b = sample_param(a, p, q + 2);
             ln = a.lines + l;
             dst = (c < nc) ? slot : -1;                         // components >= int(p[startind]) are skipped (:430)
         } else {
             const int k = slot - nTargetSlots;
-            const double* q = p + 3 * k + a.endind;             // :439
-            logN = q[0]; z = q[1]; b = q[2];
+            const int q = 3 * k + a.endind;                     // :439
+            logN = sample_param(a, p, q); z = sample_param(a, p, q + 1); b = sample_param(a, p, q + 2);
             ln = a.lines + a.nlines;
             dst = (nfill_eff > 0) ? nc * a.nlines + k : -1;
         }
@@ -774,7 +798,7 @@ struct mcalf_ctx {
     unsigned long long* d_segok = nullptr;
     double dnu_seg = 0;
     // workspaces (grown on demand)
-    double *d_P = nullptr, *d_out = nullptr, *d_partial = nullptr, *d_model = nullptr, *d_bounds = nullptr;
+    double *d_P = nullptr, *d_out = nullptr, *d_partial = nullptr, *d_model = nullptr, *d_bounds = nullptr, *d_prior = nullptr;
     double *d_recs = nullptr, *d_taps = nullptr;
     SampleHdr* d_hdr = nullptr;
     size_t cap_P = 0, cap_out = 0, cap_partial = 0, cap_model = 0, cap_recs = 0, cap_taps = 0, cap_hdr = 0;
@@ -783,6 +807,9 @@ struct mcalf_ctx {
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     bool profiling = false;
+    // prior box of mcalf_set_prior (device copy in d_prior: lo[ndim] then hi[ndim])
+    bool prior_set = false;
+    int prior_int = 0;
 };
 
 static int set_err(mcalf_ctx* ctx, int code, const char* fmt, ...) {
@@ -851,7 +878,7 @@ extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_err, ctx->d_tabs, ctx->d_lines, ctx->d_wtab, ctx->d_segok,
-                    ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds, ctx->d_recs, ctx->d_taps, ctx->d_hdr};
+                    ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds, ctx->d_prior, ctx->d_recs, ctx->d_taps, ctx->d_hdr};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
@@ -1060,8 +1087,11 @@ extern "C" int mcalf_reserve(mcalf_ctx* ctx, int64_t batch) {
 }
 
 // Enqueue the fused kernel (+ finalize when tiled) on `stream`.
+// `from_cube`: dP holds unit-cube rows, mapped through the prior box while decoding; d_theta (optional)
+// receives the transformed rows.
 static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill,
-                  double* d_out, double* d_model, hipStream_t stream) {
+                  double* d_out, double* d_model, hipStream_t stream, bool from_cube = false,
+                  double* d_theta = nullptr) {
     if (batch == 0) return MCALF_OK;
     if (batch < 0 || batch * (int64_t)ctx->ntiles > 0x7fffffffLL)
         return set_err(ctx, MCALF_ERR_RANGE, "batch %lld too large", (long long)batch);
@@ -1088,6 +1118,10 @@ static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int
     a.targonly = targonly; a.mode = mode; a.jax_half = ctx->jax_half; a.onecomp_fill = onecomp_fill;
     a.specres_fixed = ctx->specres_fixed; a.contval_fixed = ctx->contval_fixed; a.velstep = ctx->velstep;
     a.log2pi = std::log(2.0 * M_PI);
+    a.prior_lo = from_cube ? ctx->d_prior : nullptr;
+    a.prior_hi = from_cube ? ctx->d_prior + ctx->ndim : nullptr;
+    a.theta_out = from_cube ? d_theta : nullptr;
+    a.prior_int = ctx->prior_int;
     const dim3 grid((unsigned)(batch * ctx->ntiles)), block(kBlock);
     if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX)
         hipLaunchKernelGGL(mcalf_sample_kernel<true>, dim3((unsigned)batch), dim3(64), 0, stream, a, (long)batch);
@@ -1202,6 +1236,53 @@ extern "C" int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batc
         return set_err(ctx, MCALF_ERR_INVALID, "onecomp: `which` must be 0 (all lines), 1 (filler) or 2+k with k < %d",
                        ctx->nlines);
     return run_host(ctx, kModeOneComp, Q, batch, 5, 0, which, nullptr, flux);
+}
+
+extern "C" int mcalf_set_prior(mcalf_ctx* ctx, const double* lo, const double* hi, int32_t int_ncomp) {
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    if (!lo || !hi) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_prior) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_prior, 2 * (size_t)ctx->ndim * sizeof(double)));
+    // synchronous copies: the caller's arrays are borrowed for this call only, and a later *_device call may
+    // run on any stream
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_prior, lo, ctx->ndim * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_prior + ctx->ndim, hi, ctx->ndim * sizeof(double), hipMemcpyHostToDevice));
+    ctx->prior_set = true;
+    ctx->prior_int = int_ncomp ? 1 : 0;
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_loglike_cube_batch_device(mcalf_ctx* ctx, const double* dcube, int64_t batch, double* dtheta,
+                                               double* dlogL, void* stream) {
+    if (!ctx || (batch > 0 && (!dcube || !dlogL))) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    if (!ctx->prior_set) return set_err(ctx, MCALF_ERR_INVALID, "mcalf_set_prior has not been called");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch(ctx, kModeLogL, dcube, batch, 0, 0, dlogL, nullptr, (hipStream_t)stream, true, dtheta);
+}
+
+extern "C" int mcalf_loglike_cube_batch(mcalf_ctx* ctx, const double* cube, int64_t batch, double* theta,
+                                        double* logL) {
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    if (batch < 0) return set_err(ctx, MCALF_ERR_INVALID, "negative batch");
+    if (!ctx->prior_set) return set_err(ctx, MCALF_ERR_INVALID, "mcalf_set_prior has not been called");
+    if (batch == 0) return MCALF_OK;
+    if (!cube || !logL) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t total = (size_t)batch * ctx->ndim;
+    int rc;
+    if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, total))) return rc;
+    if ((rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
+    if (theta && (rc = grow(ctx, &ctx->d_model, &ctx->cap_model, total))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_P, cube, total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = launch(ctx, kModeLogL, ctx->d_P, batch, 0, 0, ctx->d_out, nullptr, ctx->stream, true,
+                theta ? ctx->d_model : nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(logL, ctx->d_out, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (theta)
+        HIP_TRY(ctx, hipMemcpyAsync(theta, ctx->d_model, total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MCALF_OK;
 }
 
 extern "C" int mcalf_scale_cube_batch(mcalf_ctx* ctx, const double* lo, const double* hi, const double* cube,

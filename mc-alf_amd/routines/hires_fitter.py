@@ -265,6 +265,24 @@ class als_fitter:
             cubes.shape[0], int(bool(int_ncomp)), out.ctypes.data_as(pd)), self._ctx)
         return out
 
+    def loglike_cube_batch(self, cubes, int_ncomp=True, return_theta=True):
+        """Unit cube in -> (theta, logL) out: lnlhood_pc(_scale_cube_pc(cube)) for every row
+        (hires_fitter.py:202-209, 250-262) in one device pass; the prior transform runs inside the
+        per-sample set-up kernel.  `int_ncomp=False` gives the MultiNest flavour (:211-216)."""
+        cubes = self._rows(cubes, self.ndim)
+        pd = C.POINTER(C.c_double)
+        key = bool(int_ncomp)
+        if getattr(self, "_prior_key", None) != key:
+            _lib.check(self._lib.mcalf_set_prior(self._ctx, self._lo.ctypes.data_as(pd),
+                                                 self._hi.ctypes.data_as(pd), int(key)), self._ctx)
+            self._prior_key = key
+        logL = np.empty(cubes.shape[0])
+        theta = np.empty_like(cubes) if return_theta else None
+        _lib.check(self._lib.mcalf_loglike_cube_batch(
+            self._ctx, cubes.ctypes.data_as(pd), cubes.shape[0],
+            theta.ctypes.data_as(pd) if return_theta else None, logL.ctypes.data_as(pd)), self._ctx)
+        return (theta, logL) if return_theta else logL
+
     def lnprior(self, p):
         """hires_fitter.py:218-234."""
         ndim = len(p)

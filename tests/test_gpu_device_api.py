@@ -81,3 +81,49 @@ def test_context_lifecycle_and_capacity_error():
     with pytest.raises(RuntimeError, match="MCALF_ERR_RANGE"):
         mcalf_amd.als_fitter(None, [[wl[0] - 1, wl[-1] + 1]], ["CIV 1548"], [1, 1], specres=[60.0],
                              spectrum=(wl, np.ones_like(wl), np.full_like(wl, 0.02)), velstep=0.01)
+
+
+def test_cube_in_logl_out_matches_two_step_path_and_oracle():
+    """mcalf_loglike_cube_batch == lnlhood_pc(_scale_cube_pc(cube)) row by row (hires_fitter.py:202-209,
+    250-262): theta bit-equal to the numpy transform, logL bit-equal to the two-step device path and within
+    the parity tolerance of the oracle evaluated on the numpy-transformed rows."""
+    from cases import problem_from_kwargs
+    from oracle import numpy_oracle as orc
+    kw, _, seed = workloads.config("C", oracle_synth)
+    rng = np.random.default_rng(seed + 100)
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        cubes = rng.random((257, fit.ndim))
+        cubes[0, :] = 0.0                               # box corners
+        cubes[1, :] = np.nextafter(1.0, 0.0)
+        theta, logL = fit.loglike_cube_batch(cubes)
+        want_theta = np.array([fit._scale_cube_pc(c.copy()) for c in cubes])
+        assert np.array_equal(theta, want_theta)
+        assert np.array_equal(logL, fit.loglike_batch(want_theta))
+        only = fit.loglike_cube_batch(cubes, return_theta=False)
+        assert np.array_equal(only, logL)
+        # MultiNest flavour: the ncomp slot stays fractional in theta, int() happens in the decode
+        theta_mn, logL_mn = fit.loglike_cube_batch(cubes, int_ncomp=False)
+        assert np.array_equal(theta_mn, np.array([fit._scale_cube_mn(c.copy(), fit.ndim, fit.ndim) for c in cubes]))
+        assert np.array_equal(logL_mn, logL)
+        # device-pointer flavour on torch's stream, without theta
+        dc = torch.from_numpy(cubes).cuda()
+        out = torch.empty(cubes.shape[0], dtype=torch.float64, device="cuda")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(fit._lib.mcalf_loglike_cube_batch_device(fit._ctx, dc.data_ptr(), cubes.shape[0], None,
+                                                            out.data_ptr(), st), fit._ctx)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), logL_mn)
+    prob = problem_from_kwargs(kw)
+    want = orc.loglike_batch(prob, np.array([orc.scale_cube_pc(prob, c) for c in cubes[:40]]))
+    assert np.max(np.abs(logL[:40] - want)) < 1e-4
+
+
+def test_cube_entry_requires_a_prior():
+    kw, _, _ = workloads.config("A")
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        cube = np.full((1, fit.ndim), 0.5)
+        out = np.empty(1)
+        pd = C.POINTER(C.c_double)
+        rc = fit._lib.mcalf_loglike_cube_batch(fit._ctx, cube.ctypes.data_as(pd), 1, None, out.ctypes.data_as(pd))
+        assert rc == _lib.MCALF_ERR_INVALID
+        assert b"mcalf_set_prior" in fit._lib.mcalf_last_error(fit._ctx)
