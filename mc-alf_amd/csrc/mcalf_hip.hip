@@ -219,6 +219,13 @@ __device__ inline void build_line_record(double* rec, double logN, double z, dou
     double uthr = (double)__powf(fmaxf(q, 1.0f), 0.1f) * 1.02;                 // 2 % margin over the float estimate
     uthr = fmax(uthr, sqrt(rec[2]) * 1.0000001);                              // never inside the core table's range
     rec[7] = (flag != 0.0 || !(uthr < 1e30)) ? INFINITY : uthr;               // never interpolate the general path
+    // |1+z| beyond 1e100 (or infinite): every |u| overflows, the reference's wofz returns 0 and the line adds
+    // nothing (tau < 1e-200).  Written out as a record that contributes exact zeros, because 1/u^2 -> 0 would
+    // put 0 * inf = NaN through the reciprocal's Newton step.  NaN parameters still propagate as NaN.
+    if (!(fabs(zp1) < 1e100) && zp1 == zp1 && fabs(K) < 1e100 && fabs(a) < 1e100) {
+        rec[0] = 0.0; rec[1] = -1e6; rec[2] = 36.0; rec[3] = 0.0; rec[4] = 0.0; rec[5] = 0.0; rec[6] = 0.0;
+        rec[7] = 0.0;
+    }
 }
 
 #ifdef MCALF_STAMPS   // diagnostic builds only (tools/): per-workgroup phase timestamps

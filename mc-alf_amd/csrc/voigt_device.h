@@ -59,8 +59,9 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return fma(r, fma(-x, r, 1.0), r);
 }
 
-// ---- general path: any y >= 0 (used when y > 2^-8 or for absurd columns) ----------------
-__device__ __noinline__ double hjert_general(double x, double y) {
+// ---- general path: y > 2^-8, absurd columns, and y < 0 (a negative Doppler parameter) ------
+// Upper half plane, x >= 0.
+__device__ __forceinline__ double hjert_upper(double x, double y) {
     const double x2 = x * x, y2 = y * y;
     if (x2 + y2 >= 64.0) {
         // Laplace asymptotic series  w(z) ~ (i/sqrt(pi)) (1/z) sum_k (2k-1)!!/(2 z^2)^k ,
@@ -104,6 +105,14 @@ __device__ __noinline__ double hjert_general(double x, double y) {
     }
     S1 *= G;
     return T1 + T2 + (2.0 * h * y / M_PI) * fma(-c2, S1, 0.5 * S23);
+}
+
+// Any real y (x >= 0).  Lower half plane by reflection, w(z) = 2 exp(-z^2) - w(-z), which is what
+// scipy.special.wofz returns there (the reference reaches it with b < 0: a = gamma/(4 pi dnu) < 0).
+__device__ __noinline__ double hjert_general(double x, double y) {
+    if (!(y < 0.0)) return hjert_upper(x, y);
+    const double ay = -y;
+    return 2.0 * exp((ay - x) * (x + ay)) * cos(2.0 * x * ay) - hjert_upper(x, ay);
 }
 
 // Full H(x, y) with exactly the kernel's arithmetic for a line of optical-depth scale K = 1

@@ -344,8 +344,15 @@ class als_fitter:
         return out
 
     # ------------------------------------------------------------------ reference callables
+    def _check_scalar(self, p):
+        """The single-point callables of the reference raise where Python's `int()` does: a NaN or
+        infinite ncomp slot (`int(p[startind])`, :428) is a ValueError / OverflowError, not a value.
+        (The batched entries clamp the slot to [0, ncompmax] instead and never raise.)"""
+        int(p[self.startind])
+
     def chi2(self, p):
         """hires_fitter.py:236-248 (returns `(+inf, [])` for an all-zero model, else a float)."""
+        self._check_scalar(p)
         v = float(self.chi2_batch(p)[0])
         if v == np.inf:
             return +np.inf, []
@@ -366,10 +373,12 @@ class als_fitter:
 
     def lnlhood_worker(self, p):
         """hires_fitter.py:287-328."""
+        self._check_scalar(p)
         return float(self.loglike_batch(p)[0])
 
     def reconstruct_spec(self, p, targonly=False):
         """hires_fitter.py:409-449."""
+        self._check_scalar(p)
         return self.model_batch(p, targonly)[0]
 
     def reconstruct_onecomp(self, specresolution, continuum, N, z, b):

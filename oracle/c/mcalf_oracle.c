@@ -37,8 +37,18 @@ static double erfcx_pos(double y) {
     return (1.0 / (y * 1.7724538509055160273)) * (1.0 - 0.5 * t * (1.0 - 1.5 * t * (1.0 - 2.5 * t)));
 }
 
+static double re_w_upper(double x, double y);
+
+/* Re w(x + i y) for any real y: lower half plane by w(z) = 2 exp(-z^2) - w(-z) (what scipy's
+ * Faddeeva code does; reached when b < 0 makes the damping parameter negative, :360-361). */
 static double re_w(double x, double y) {
     x = fabs(x);
+    if (!(y < 0.0)) return re_w_upper(x, y);
+    const double ay = -y;
+    return 2.0 * exp((ay - x) * (x + ay)) * cos(2.0 * x * ay) - re_w_upper(x, ay);
+}
+
+static double re_w_upper(double x, double y) {
     const double x2 = x * x, y2 = y * y;
     if (x2 + y2 >= 64.0) {
         const double ir2 = 1.0 / (x2 + y2);

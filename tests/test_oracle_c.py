@@ -46,3 +46,15 @@ def test_c_oracle_matches_numpy_oracle_on_random_draws_and_threads():
     for threads in (1, 4):
         got = c_oracle.COracle(prob, threads=threads).loglike_batch(P)
         assert (np.abs(got - want) / np.abs(want)).max() < 1e-11
+
+
+def test_c_re_w_lower_half_plane_matches_scipy():
+    from scipy.special import wofz
+    d = np.loadtxt(os.path.join(GOLD, "civ_mock_spec.txt"))
+    co = c_oracle.COracle(o.Problem(d[:, 0], d[:, 1], d[:, 2], o.CIV_LINES, (1, 1), specres=[8.0]))
+    x = np.linspace(0, 30, 601)
+    for yv in (-1e-5, -3.25e-3, -0.7, -3.0):
+        got = np.array([co.re_w(float(xx), yv) for xx in x])
+        ref = wofz(x + 1j * yv).real
+        scale = np.maximum(np.abs(ref), np.abs(2 * np.exp(yv * yv - x * x)))
+        assert np.max(np.abs(got - ref) / scale) < 5e-13
