@@ -89,13 +89,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    # MCALF_BENCH_FORCE_DIST=1 (with torch.distributed.run --nproc-per-node 1) runs the N>1 code path --
+    # process group, RCCL gather ring, barrier, all_reduce -- on a single rank: a one-GPU check of the
+    # collective plumbing the driver's multi-GPU runs use.
+    use_dist = world > 1 or os.environ.get("MCALF_BENCH_FORCE_DIST") == "1"
     rehearsal = world > 1 and args.backend == "gloo"
     if rehearsal:
         local_rank = 0                                   # every rank on the one GPU of the box
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -115,9 +120,9 @@ def main():
 
     dP = torch.from_numpy(P_host).to(dev)
     # two logL buffers in flight: the (latency-bound) gather of step k overlaps the kernel of step k+1
-    plan = mdist.LogLGather(batch * world, "cpu" if rehearsal else dev, depth=2)
+    plan = mdist.LogLGather(batch * world, "cpu" if rehearsal else dev, depth=2, always_collective=use_dist)
     assert (plan.lo, plan.hi) == (rank * batch, (rank + 1) * batch)
-    dlogL = torch.empty(batch, dtype=torch.float64, device=dev) if (rehearsal or world == 1) else None
+    dlogL = torch.empty(batch, dtype=torch.float64, device=dev) if (rehearsal or not use_dist) else None
     _lib.check(fit._lib.mcalf_reserve(fit._ctx, batch), fit._ctx)
     stream = torch.cuda.current_stream()
     st = C.c_void_p(stream.cuda_stream)
@@ -152,14 +157,16 @@ def main():
         if rc:
             _lib.check(rc, ctx)
         last_out[0] = out
-        if world > 1:
+        if use_dist:
             if rehearsal:
                 plan.local.copy_(dlogL)                  # through host memory (gloo)
             plan.gather_async()                          # RCCL gather of the logL shards to rank 0
 
+    gathered = [None]
+
     def fence():
-        if world > 1:
-            plan.finish()                                # every outstanding gather has landed on rank 0
+        if use_dist:
+            gathered[0] = plan.finish()                  # every outstanding gather has landed on rank 0
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -177,7 +184,7 @@ def main():
     red_dev = "cpu" if rehearsal else dev
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     tot = torch.tensor([comp_pix, line_pix], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
@@ -198,6 +205,13 @@ def main():
         _lib.check(fit._lib.mcalf_profile_end(fit._ctx, C.byref(kern_ms), C.byref(nl)), fit._ctx)
     kern_ms = kern_ms.value if nl.value else stream_ms      # mean duration of mcalf_fused_kernel alone
     logL_dev = last_out[0].cpu().numpy()
+    gather_check = None
+    if use_dist and rank == 0 and gathered[0] is not None:
+        # the vector rank 0 holds after the last gather: its own block must be what it computed, and every
+        # other block a finite logL of that rank's rows
+        g = gathered[0].cpu().numpy()
+        gather_check = {"rows": int(g.size), "own_block_equal": bool(np.array_equal(g[:batch], logL_dev)),
+                        "all_finite": bool(np.isfinite(g).all())}
 
     out = None
     if rank == 0:
@@ -270,8 +284,10 @@ def main():
                     "value": reps * float(nc[: len(rows)].sum()) * npix / dtc, "unit": "evals/s", "cores": nthr, "kind": "port",
                     "sample": f"{reps} x {len(rows)} rows, oracle/c/mcalf_oracle.c (gcc -O2 -fopenmp), {dtc:.1f} s",
                     "max_abs_dlogL_vs_gpu": float(np.abs(cvals - logL_dev[: len(rows)]).max())}
+    if out is not None and gather_check is not None:
+        out["gather_check"] = gather_check
     fit.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
