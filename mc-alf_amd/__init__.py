@@ -6,6 +6,7 @@ The directory name contains a hyphen; `import mcalf_amd` (the alias module at th
 repository root) resolves to this package.
 """
 from . import _lib  # noqa: F401
+from . import adapters  # noqa: F401
 from . import dist  # noqa: F401
 from . import routines  # noqa: F401
 from . import workloads  # noqa: F401

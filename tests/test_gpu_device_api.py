@@ -127,3 +127,17 @@ def test_cube_entry_requires_a_prior():
         rc = fit._lib.mcalf_loglike_cube_batch(fit._ctx, cube.ctypes.data_as(pd), 1, None, out.ctypes.data_as(pd))
         assert rc == _lib.MCALF_ERR_INVALID
         assert b"mcalf_set_prior" in fit._lib.mcalf_last_error(fit._ctx)
+
+
+def test_batch_pool_turns_a_sampler_map_into_one_device_call():
+    from mcalf_amd import adapters
+    kw, _, seed = workloads.config("A")
+    P = workloads.draw_P(kw, 64, np.random.default_rng(seed))
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        pool = adapters.BatchPool(fit, size=64)
+        got = pool.map(fit.lnlhood_dy, list(P))
+        assert got == [float(v) for v in fit.loglike_batch(P)] and pool.batched_calls == 1
+        assert got[:3] == [fit.lnlhood_dy(p) for p in P[:3]]
+        loglike, transform = adapters.batch_functions(fit)
+        cubes = np.random.default_rng(3).random((16, fit.ndim))
+        assert np.array_equal(loglike(transform(cubes)), fit.loglike_cube_batch(cubes)[1])
