@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             tj += add;
         }
         const int pos = tid + j * kBlock - shift;
-        if (pos >= 0 && pos < extTight) sF[tile_pos(pos)] = exp(-tj);    // :377 (product of exp == exp of sum)
+        if (pos >= 0 && pos < extTight) sF[tile_pos(pos)] = exp_neg(tj);    // :377 (product of exp == exp of sum)
         __builtin_amdgcn_sched_barrier(0);             // keep the 8 broadcast reads of one j from piling up
     }
     if (tid < kTileSlack) sF[tile_pos(extTight + tid)] = 0.0;

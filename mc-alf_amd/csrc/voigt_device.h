@@ -59,6 +59,39 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return fma(r, fma(-x, r, 1.0), r);
 }
 
+// d = a * b + c with c held in a scalar register pair.  The compiler otherwise materialises every 64-bit
+// polynomial constant with two v_mov_b32 per use (as costly on the vector pipe as the FMA itself); scalar
+// moves are free next to a saturated VALU and are shared by the thread's 8 pixels.
+__device__ __forceinline__ double fma_sconst(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+
+// exp(-t): the argument reduction and degree-11 polynomial of the ROCm device library's exp (n =
+// rint(x log2 e), r = x - n ln2_hi - n ln2_lo, 2^n p(r)), with the constants in scalar registers.
+// Same result as exp(-t) to the last bit (tools/micro/exp_test.hip), including exp(-inf) = 0,
+// exp(+inf) = inf and NaN.
+__device__ __forceinline__ double exp_neg(double t) {
+    const double n = __builtin_rint(t * -0x1.71547652b82fep+0);            // x log2(e), x = -t
+    double r = fma(n, -0x1.62e42fefa39efp-1, -t);                          // x - n ln2_hi
+    r = fma(n, -0x1.abc9e3b39803fp-56, r);                                 //   - n ln2_lo
+    double p = fma_sconst(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+    p = fma_sconst(r, p, 0x1.71dee623fde64p-19);
+    p = fma_sconst(r, p, 0x1.a01997c89e6b0p-16);
+    p = fma_sconst(r, p, 0x1.a01a014761f6ep-13);
+    p = fma_sconst(r, p, 0x1.6c16c1852b7b0p-10);
+    p = fma_sconst(r, p, 0x1.1111111122322p-7);
+    p = fma_sconst(r, p, 0x1.55555555502a1p-5);
+    p = fma_sconst(r, p, 0x1.5555555555511p-3);
+    p = fma_sconst(r, p, 0x1.000000000000bp-1);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    double v = ldexp(p, (int)n);
+    v = (t < -1024.0) ? INFINITY : v;
+    return (t > 1075.0) ? 0.0 : v;
+}
+
 // ---- general path: y > 2^-8, absurd columns, and y < 0 (a negative Doppler parameter) ------
 // Upper half plane, x >= 0.
 __device__ __forceinline__ double hjert_upper(double x, double y) {
