@@ -539,31 +539,46 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     }
     // far-wing interpolation state: this lane's node pixel, the wave's interpolable segments
     double nuNode = 0.0, farNode = 0.0;
-    unsigned long long segOk = 0;
+    unsigned long long segOk = 0, tileMask = 0;
     if (kFarInterp) {
         const int wv = tid >> 6, ln = tid & 63;
         int e = ext0 + 64 * wv + kBlock * (ln >> 3) + VT_INTERP_NODES[ln & 7];
         if (e < 0 || e >= a.npix) { e %= a.npix; if (e < 0) e += a.npix; }      // such segments are never interpolated
         nuNode = a.nu[e];
-        const unsigned long long tileMask = a.segok[tileIdx];                  // bit m = segment m = wave + 8 j
-#pragma unroll
-        for (int j = 0; j < kPpt; ++j) segOk |= ((tileMask >> (wv + 8 * j)) & 1ULL) << (8 * j);
-        segOk = uniform64(segOk);
+        tileMask = a.segok[tileIdx];                                           // bit m = segment m = wave + 8 j
     }
 
     MCALF_SUB(1);
     // ---- 1. per-sample set-up comes from mcalf_sample_kernel: header, records, taps -----------------
+    // Every global load of the set-up is issued before the first one is consumed (one memory round trip
+    // instead of three): the record and tap copies run to their provisioned sizes, which do not depend on
+    // the header (slots beyond the sample's own counts hold stale values that are never read).
     const SampleHdr hd = a.hdr[s];
+    constexpr int kRecRegs = 2;                        // covers ncl_cap <= 128 without a second trip
+    const int recTotal = a.ncl_cap * kRecStride, tapTotal = 2 * a.n_cap + 8;
+    const double* gr = a.recs + (size_t)s * recTotal;
+    const double* gt = a.taps + (size_t)s * tapTotal;
+    double rreg[kRecRegs];
+#pragma unroll
+    for (int i = 0; i < kRecRegs; ++i) rreg[i] = (tid + i * kBlock < recTotal) ? gr[tid + i * kBlock] : 0.0;
+    const double treg0 = (tid < tapTotal) ? gt[tid] : 0.0;
+
+    if (kFarInterp) {
+        const int wv = tid >> 6;
+#pragma unroll
+        for (int j = 0; j < kPpt; ++j) segOk |= ((tileMask >> (wv + 8 * j)) & 1ULL) << (8 * j);
+        segOk = uniform64(segOk);
+    }
     const double cont = hd.cont, bot = hd.bot;
     const int ncl = hd.ncl, n = hd.n;
     const bool bad = hd.bad != 0;
     const int ntap8 = (2 * n + 1 + 7) & ~7;
-    {
-        const double* gr = a.recs + (size_t)s * a.ncl_cap * kRecStride;
-        for (int i = tid; i < ncl * kRecStride; i += kBlock) sRec[i] = gr[i];
-        const double* gt = a.taps + (size_t)s * (2 * a.n_cap + 8);
-        for (int i = tid; i < ntap8; i += kBlock) sW[i] = gt[i];
-    }
+#pragma unroll
+    for (int i = 0; i < kRecRegs; ++i)
+        if (tid + i * kBlock < recTotal) sRec[tid + i * kBlock] = rreg[i];
+    for (int i = tid + kRecRegs * kBlock; i < recTotal; i += kBlock) sRec[i] = gr[i];
+    if (tid < tapTotal) sW[tid] = treg0;
+    for (int i = tid + kBlock; i < tapTotal; i += kBlock) sW[i] = gt[i];
     MCALF_SUB(2);
 #pragma unroll
     for (int i = 0; i < kTRegs; ++i) {
