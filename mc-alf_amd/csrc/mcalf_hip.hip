@@ -190,9 +190,9 @@ __device__ __forceinline__ double pow10_fast(double x) {
     return fma(r, e, r);
 }
 
-// Record per (component,line): [A, B, x2c, y, K, Kyt, flag, uthr]
+// Record per (component,line): [A, B, x2c, y, K, Kyt, Kgen, uthr]   (general-path lines: [A, B, y, 0, 0, 0, K, 0])
 //   u = nu*A - B;  tau += K H(u, y);  Kyt = K y / sqrt(pi) scales the wing polynomials;
-//   x2c: below it the core table (with exp(-x^2)) is used;  flag != 0 -> general path;
+//   x2c: below it the core table (with exp(-x^2)) is used;  Kgen != 0 -> general path (eval_general_lines);
 //   uthr: a 64-pixel segment whose pixels all have |u| >= uthr is evaluated at 8 nodes and interpolated.
 __device__ inline void build_line_record(double* rec, double logN, double z, double b_kms, const LineDev& ln,
                                          double dnu_seg) {
@@ -211,14 +211,20 @@ __device__ inline void build_line_record(double* rec, double logN, double z, dou
     double flag = 0.0;
     if (!(a <= kYFastMax) || !(a >= 0.0)) flag = 1.0;    // general path (also NaN)
     else if (K * 1.6e-28 > 2e-17) flag = 1.0;            // absurd columns: exp(-x^2) matters past |x| = 8
-    rec[6] = flag;
+    rec[6] = 0.0;
     // interpolation error kInterpC (du/u0)^8 Kyt/u0^2 <= kInterpTol  ->  u0^10 >= kInterpC Kyt du^8 / tol
     const float du = (float)(rec[0] * dnu_seg);
     const float du2 = du * du, du4 = du2 * du2;
     const float q = (float)(kInterpC / kInterpTol) * (float)rec[5] * du4 * du4;
     double uthr = (double)__powf(fmaxf(q, 1.0f), 0.1f) * 1.02;                 // 2 % margin over the float estimate
     uthr = fmax(uthr, sqrt(rec[2]) * 1.0000001);                              // never inside the core table's range
-    rec[7] = (flag != 0.0 || !(uthr < 1e30)) ? INFINITY : uthr;               // never interpolate the general path
+    rec[7] = !(uthr < 1e30) ? INFINITY : uthr;
+    if (flag != 0.0) {
+        // General-path line: the hot loop carries no test for it.  Its fast-path view is a line of zero
+        // strength (folded tables all zero, every segment "interpolated"), and eval_general_lines() finds
+        // the real damping parameter in slot 2 and the real K in slot 6 (K != 0 marks the record).
+        rec[2] = a; rec[3] = 0.0; rec[4] = 0.0; rec[5] = 0.0; rec[6] = K; rec[7] = 0.0;
+    }
     // |1+z| beyond 1e100 (or infinite): every |u| overflows, the reference's wofz returns 0 and the line adds
     // nothing (tau < 1e-200).  Written out as a record that contributes exact zeros, because 1/u^2 -> 0 would
     // put 0 * inf = NaN through the reciprocal's Newton step.  NaN parameters still propagate as NaN.
@@ -258,7 +264,6 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
                                           const double (&nu)[kPpt], double (&tau)[kPpt], double nuNode,
                                           double& farNode, unsigned long long segOk) {
     const double A = rec[0], B = rec[1], x2c = rec[2];
-    if (rec[6] != 0.0) return;                        // general-path line: handled by eval_general_lines()
     double cF[VT_FDEG + 1];
 #pragma unroll
     for (int k = 0; k <= VT_FDEG; ++k) cF[k] = tab[kZFLds + k];
@@ -305,32 +310,35 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
         if ((done >> (8 * j)) & 1ULL) continue;       // whole segment interpolated (wave-uniform)
         const double u = fma(nu[j], A, -B);
         const double x2 = u * u;
+        // Every branch leaves (t, P) with contribution t * P, and the running optical depth is updated at ONE
+        // place after the branches merge: an update inside each branch makes the compiler copy tau[j] into a
+        // scratch pair and back (3 vector moves per evaluation).
+        double t, P;
         if (x2 >= kX2Far) {                           // |u| >= 16
-            const double t = fast_rcp(x2);
-            double P = cF[VT_FDEG];
+            t = fast_rcp(x2);
+            P = cF[VT_FDEG];
 #pragma unroll
             for (int k = VT_FDEG - 1; k >= 0; --k) P = fma(P, t, cF[k]);
-            fmac_inplace(tau[j], t, P);
         } else if (x2 >= x2c) {                       // exp(-u^2) gone: polynomial in 1/u^2
-            const double t = fast_rcp(x2);
+            t = fast_rcp(x2);
             const bool z0 = x2 >= kX2Wing;
             const double sv = z0 ? t : fma(t, VT_Z1_A, VT_Z1_B);
             const double* cw = tab + (z0 ? kZ0Lds : VT_Z1_OFF);
-            double P = cw[VT_WDEG];
+            P = cw[VT_WDEG];
 #pragma unroll
             for (int k = VT_WDEG - 1; k >= 0; --k) P = fma(P, sv, cw[k]);
-            fmac_inplace(tau[j], t, P);
         } else {                                      // core table (per-lane LDS gather)
             const double x = fabs(u);
             int jx = (int)(x * 4.0);
             jx = min(max(jx, 0), VT_NINT - 1);
             const double sv = fma(x, 8.0, -(double)(2 * jx + 1));
             const double* cc = tab + jx * VT_CSTRIDE;
-            double P = cc[VT_CDEG];
+            P = cc[VT_CDEG];
 #pragma unroll
             for (int k = VT_CDEG - 1; k >= 0; --k) P = fma(P, sv, cc[k]);
-            add_inplace(tau[j], P);
+            t = 1.0;                                  // tau += 1 * P rounds exactly like tau += P
         }
+        fmac_inplace(tau[j], t, P);
     }
 }
 
@@ -476,7 +484,7 @@ __device__ __forceinline__ void eval_general_lines(const double* __restrict__ sR
     for (int cl = 0; cl < ncl; ++cl) {
         const double* rec = sRec + cl * kRecStride;
         if (rec[6] == 0.0) continue;
-        const double A = rec[0], B = rec[1], y = rec[3], K = rec[4];
+        const double A = rec[0], B = rec[1], y = rec[2], K = rec[6];
 #pragma unroll 1
         for (int j = 0; j < kPpt; ++j) {
             const double u = fma(nu[j], A, -B);

@@ -19,6 +19,8 @@ def synth(kw, p):
 
 
 kw, batch, seed = workloads.config(sys.argv[1] if len(sys.argv) > 1 else "B", synth)
+if len(sys.argv) > 2:
+    batch = int(sys.argv[2])
 P = workloads.draw_P(kw, batch, np.random.default_rng(seed))
 fit = mcalf_amd.als_fitter(None, **kw)
 for _ in range(3):
