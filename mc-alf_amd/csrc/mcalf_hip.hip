@@ -278,8 +278,10 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
         const double un = fma(nuNode, A, -B);
         unsigned long long mp = __builtin_amdgcn_ballot_w64(un >= uthr);
         unsigned long long mn = __builtin_amdgcn_ballot_w64(un <= -uthr);
-        mp &= mp >> 1; mp &= mp >> 2; mp &= mp >> 4;          // bit 8j = AND of byte j
-        mn &= mn >> 1; mn &= mn >> 2; mn &= mn >> 4;
+        // u is monotonic along a segment (segOk excludes the wrapped ones), so its two END nodes -- lanes 8j
+        // and 8j+7, the segment's first and last pixel -- decide for all eight.
+        mp &= mp >> 7;                                        // bit 8j = first and last node
+        mn &= mn >> 7;
         done = uniform64((mp | mn) & segOk & 0x0101010101010101ULL);
 #ifdef MCALF_COUNT_INTERP
         if ((threadIdx.x & 63) == 0) { atomicAdd(&g_dbg[0], (unsigned long long)__popcll(done)); atomicAdd(&g_dbg[1], 8ULL); atomicAdd(&g_dbg[2], (unsigned long long)__popcll(segOk)); }
