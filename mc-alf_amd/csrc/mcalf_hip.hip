@@ -287,8 +287,8 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
         if ((threadIdx.x & 63) == 0) { atomicAdd(&g_dbg[0], (unsigned long long)__popcll(done)); atomicAdd(&g_dbg[1], 8ULL); atomicAdd(&g_dbg[2], (unsigned long long)__popcll(segOk)); }
 #endif
         if (done != 0) {                                      // wave-uniform
-            const unsigned long long lanes = done * 0xFFULL;  // byte j -> 0xFF: one bit per lane
-            const bool mine = (lanes >> (threadIdx.x & 63)) & 1ULL;
+            const unsigned long long lanes = (done << 8) - done;     // byte j -> 0xFF: one bit per lane
+            const bool mine = __builtin_amdgcn_inverse_ballot_w64(lanes);   // the scalar mask IS the lane predicate
             const double x2n = un * un;
             const double t = fast_rcp(fmax(x2n, kX2Mid));     // lanes outside `mine` only need to stay finite
             double P;
@@ -309,7 +309,7 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
     }
 #pragma unroll
     for (int j = 0; j < kPpt; ++j) {
-        if ((done >> (8 * j)) & 1ULL) continue;       // whole segment interpolated (wave-uniform)
+        if (__builtin_expect((done >> (8 * j)) & 1ULL, 1)) continue;   // whole segment interpolated (wave-uniform, the usual case)
         const double u = fma(nu[j], A, -B);
         const double x2 = u * u;
         // Every branch leaves (t, P) with contribution t * P, and the running optical depth is updated at ONE
