@@ -276,6 +276,9 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
     if (kFarInterp) {
         const double uthr = rec[7];
         const double un = fma(nuNode, A, -B);
+        // issued ahead of the scalar mask chain below, which then runs in the shadow of the reciprocal
+        const double x2n = un * un;
+        const double t = fast_rcp(fmax(x2n, kX2Mid));         // lanes outside `mine` only need to stay finite
         unsigned long long mp = __builtin_amdgcn_ballot_w64(un >= uthr);
         unsigned long long mn = __builtin_amdgcn_ballot_w64(un <= -uthr);
         // u is monotonic along a segment (segOk excludes the wrapped ones), so its two END nodes -- lanes 8j
@@ -289,8 +292,6 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
         if (done != 0) {                                      // wave-uniform
             const unsigned long long lanes = (done << 8) - done;     // byte j -> 0xFF: one bit per lane
             const bool mine = __builtin_amdgcn_inverse_ballot_w64(lanes);   // the scalar mask IS the lane predicate
-            const double x2n = un * un;
-            const double t = fast_rcp(fmax(x2n, kX2Mid));     // lanes outside `mine` only need to stay finite
             double P;
             if (uthr >= VT_XFAR || x2n >= kX2Far) {               // (first test is uniform: strong lines only ever use zone F)
                 P = cF[VT_FDEG];
@@ -615,12 +616,10 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
 #if MCALF_BALANCE_PRIO
         // Wave priority falls as the workgroup progresses, so of the two workgroups sharing a CU the one
         // that is behind gets the issue slots (they finish together instead of the older one first).
-        switch ((4 * cl0) / ncl_run) {
-            case 0: __builtin_amdgcn_s_setprio(3); break;
-            case 1: __builtin_amdgcn_s_setprio(2); break;
-            case 2: __builtin_amdgcn_s_setprio(1); break;
-            default: __builtin_amdgcn_s_setprio(0); break;
-        }
+        if (4 * cl0 < ncl_run) __builtin_amdgcn_s_setprio(3);
+        else if (4 * cl0 < 2 * ncl_run) __builtin_amdgcn_s_setprio(2);
+        else if (4 * cl0 < 3 * ncl_run) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
 #endif
         double* tabs = sTab + buf * (kLinesPerSync * kTabPad);
         if (hasCoef) {
@@ -629,10 +628,10 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             for (int nn = 0; nn < VT_NY; ++nn) Tn[nn] = sT[nn * VT_NTOT + tid];
 #pragma unroll
             for (int l = 0; l < kLinesPerSync; ++l) {
-                if (cl0 + l < ncl_run) {
-                    const double* rec = sRec + (cl0 + l) * kRecStride;
-                    tabs[l * kTabPad + coefPos] = fold_coef(Tn, rec[3], coreCoef ? rec[4] : rec[5]);
-                }
+                // no test per line: past the last record the last one is folded again into a slot nobody
+                // reads, which keeps the group's folds independent chains the scheduler can interleave
+                const double* rec = sRec + min(cl0 + l, ncl_run - 1) * kRecStride;
+                tabs[l * kTabPad + coefPos] = fold_coef(Tn, rec[3], coreCoef ? rec[4] : rec[5]);
             }
         }
         __syncthreads();
