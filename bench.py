@@ -75,6 +75,7 @@ def main():
                          "one-GPU box (all ranks share cuda:0, logL shards gathered through host memory)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads of the second CPU baseline (plain-C/OpenMP oracle); 0 = skip it")
+    ap.add_argument("--pinned", action="store_true", help="with --host-api: P and logL in page-locked host memory")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent batches kept in flight (contexts + streams); 1 = the headline configuration")
     ap.add_argument("--no-launch-events", action="store_true",
@@ -135,13 +136,17 @@ def main():
             s2 = torch.cuda.Stream()
             extra.append((f2, s2, torch.empty(batch, dtype=torch.float64, device=dev)))
     turn = [0]
+    P_host_api, out_host_api = P_host, None
+    if args.host_api and args.pinned:                    # page-locked host buffers: the copies become plain DMA
+        P_host_api = torch.from_numpy(P_host).pin_memory().numpy()
+        out_host_api = torch.empty(batch, dtype=torch.float64).pin_memory().numpy()
     launch = fit._lib.mcalf_loglike_batch_device
     ctx, pP = fit._ctx, dP.data_ptr()
     last_out = [dlogL]
 
     def step():
         if args.host_api:
-            fit.loglike_batch(P_host)
+            fit.loglike_batch(P_host_api, out=out_host_api)
             return
         if extra:
             k = turn[0] % (len(extra) + 1)
@@ -234,7 +239,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic", "batches_in_flight": max(1, args.inflight if (world == 1 and not args.host_api) else 1), "entry": "host pointers (PCIe inclusive)" if args.host_api else "device pointers",
+            "dtype": "f64", "data": "synthetic", "batches_in_flight": max(1, args.inflight if (world == 1 and not args.host_api) else 1), "entry": ("host pointers (PCIe inclusive%s)" % (", page-locked buffers" if args.pinned else "")) if args.host_api else "device pointers",
             "config": {"workload": f"BASELINE config {args.config}: CIV 1548/1550 synthetic spectrum" if args.config != "E"
                        else "BASELINE config E: HI 1215 damped", "batch_per_gpu": batch, "global_batch": batch * world,
                        "npix": npix, "ncomp": list(kw["ncomp"]), "nlines": nlines, "nfill": fit.nfill, "ndim": ndim,

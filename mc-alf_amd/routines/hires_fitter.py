@@ -306,10 +306,16 @@ class als_fitter:
             raise ValueError(f"parameter rows must have {width} entries, got {P.shape[1]}")
         return P
 
-    def loglike_batch(self, P):
-        """logL[i] = lnlhood_worker(P[i]) for every row."""
+    def loglike_batch(self, P, out=None):
+        """logL[i] = lnlhood_worker(P[i]) for every row.  `out` (float64, C-contiguous, one entry per
+        row) is filled in place when given; with `P` and `out` in page-locked host memory (e.g.
+        `torch.empty(..., pin_memory=True).numpy()`) the two PCIe copies of the call are DMA transfers
+        instead of staged ones."""
         P = self._rows(P, self.ndim)
-        out = np.empty(P.shape[0])
+        if out is None:
+            out = np.empty(P.shape[0])
+        elif out.dtype != np.float64 or not out.flags.c_contiguous or out.size != P.shape[0]:
+            raise ValueError("out must be a C-contiguous float64 array with one entry per row")
         pd = C.POINTER(C.c_double)
         _lib.check(self._lib.mcalf_loglike_batch(self._ctx, P.ctypes.data_as(pd), P.shape[0],
                                                  out.ctypes.data_as(pd)), self._ctx)

@@ -141,3 +141,19 @@ def test_batch_pool_turns_a_sampler_map_into_one_device_call():
         loglike, transform = adapters.batch_functions(fit)
         cubes = np.random.default_rng(3).random((16, fit.ndim))
         assert np.array_equal(loglike(transform(cubes)), fit.loglike_cube_batch(cubes)[1])
+
+
+def test_loglike_batch_fills_a_caller_buffer_including_page_locked_memory():
+    kw, _, seed = workloads.config("A")
+    P = workloads.draw_P(kw, 33, np.random.default_rng(seed))
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        want = fit.loglike_batch(P)
+        out = np.full(33, np.nan)
+        assert fit.loglike_batch(P, out=out) is out and np.array_equal(out, want)
+        Pp = torch.from_numpy(P).pin_memory().numpy()
+        outp = torch.empty(33, dtype=torch.float64).pin_memory().numpy()
+        fit.loglike_batch(Pp, out=outp)
+        assert np.array_equal(outp, want)
+        for bad in (np.empty(32), np.empty(33, dtype=np.float32), np.empty(66)[::2]):
+            with pytest.raises(ValueError):
+                fit.loglike_batch(P, out=bad)
