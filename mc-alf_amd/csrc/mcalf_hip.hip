@@ -838,6 +838,10 @@ struct mcalf_ctx {
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     bool profiling = false;
+    // Small host-pointer calls (the one-theta-at-a-time solvers): parameters and results travel through a
+    // page-locked, device-mapped staging block that the kernels read / write directly -- no copy commands.
+    double* h_small = nullptr;          // host address
+    double* d_small = nullptr;          // the same memory as the device sees it
     // prior box of mcalf_set_prior (device copy in d_prior: lo[ndim] then hi[ndim])
     bool prior_set = false;
     int prior_int = 0;
@@ -912,6 +916,7 @@ extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
                     ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds, ctx->d_prior, ctx->d_recs, ctx->d_taps, ctx->d_hdr};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1223,6 +1228,8 @@ extern "C" int mcalf_model_batch_device(mcalf_ctx* ctx, const double* dP, int64_
     return launch(ctx, kModeModel, dP, batch, targonly ? 1 : 0, 0, nullptr, dflux, (hipStream_t)stream);
 }
 
+constexpr size_t kSmallDoubles = 2048;      // 16 KB of parameters (and as many results) go the zero-copy way
+
 // Host-pointer entries: stage through the context's workspaces on its private stream.
 static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
                     double* out_scalar, double* out_model) {
@@ -1232,6 +1239,19 @@ static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
     if (!P || (!out_scalar && !out_model)) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc;
+    if (out_scalar && !out_model && (size_t)batch * rowlen <= kSmallDoubles && (size_t)batch <= kSmallDoubles) {
+        // zero-copy path: a single-theta call is dominated by the latency of its two copy commands
+        if (!ctx->h_small) {
+            HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_small, 2 * kSmallDoubles * sizeof(double), hipHostMallocMapped));
+            HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->d_small, ctx->h_small, 0));
+        }
+        std::memcpy(ctx->h_small, P, (size_t)batch * rowlen * sizeof(double));
+        rc = launch(ctx, mode, ctx->d_small, batch, targonly, fill, ctx->d_small + kSmallDoubles, nullptr, ctx->stream);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(out_scalar, ctx->h_small + kSmallDoubles, (size_t)batch * sizeof(double));
+        return MCALF_OK;
+    }
     if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, (size_t)batch * rowlen))) return rc;
     if (out_scalar && (rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
     if (out_model && (rc = grow(ctx, &ctx->d_model, &ctx->cap_model, (size_t)batch * ctx->npix))) return rc;
