@@ -88,3 +88,18 @@ def test_sixteen_component_lines_cap_and_saturation():
               spectrum=_spectrum(wl, rng))
     P = workloads.draw_P(kw, 7, rng)
     _check(kw, P, atol=1e-3)      # |logL| ~ 1e6 here; the 1e-10 relative bar still applies
+
+
+def test_many_records_take_the_second_record_trip():
+    """30 components x 6 lines + 3 fillers = 183 records (1464 doubles): more than the two registers per
+    thread the fused kernel's set-up holds in flight, so the remainder goes through its follow-up loop;
+    the LDS left for the flux tile shrinks and the 2600-pixel spectrum needs several tiles."""
+    rng = np.random.default_rng(14)
+    z0 = 2.2
+    wl = 1180.0 * (1 + z0) * np.exp(np.arange(2600) * 2.0 / 2.9979245e5)
+    kw = dict(fitrange=[[wl[0] - 1, wl[-1] + 1]], fitlines=["SiII %d" % int(l[0]) for l in SIII], linepars=SIII,
+              ncomp=[24, 30], nfill=3, specres=[7.0], Nrange=[11.5, 13.5], brange=[4.0, 20.0],
+              zrange=[z0 - 0.001, z0 + 0.012], spectrum=_spectrum(wl, rng), velstep=2.0)
+    P = workloads.draw_P(kw, 7, rng)
+    info = _check(kw, P)
+    assert info.ndim == 1 + 90 + 9
