@@ -1,14 +1,16 @@
 // libmcalf_hip.so -- MI355X (gfx950) implementation of the MC-ALF likelihood hot path.
 //
-// One fused kernel per call: for a workgroup = (live point s, pixel tile T)
-//   1. decode p_s, build per-(component,line) constants in LDS     hires_fitter.py:412-431,357-364
-//   2. tau(pixel) = sum_cl K_cl H(u_cl(pixel), a_cl); flux = exp(-tau) -> LDS tile with +-n halo
-//                                                                   hires_fitter.py:365,377,430-442
-//   3. sliding-window Gaussian LSF from LDS (periodic / zero-pad)   hires_fitter.py:452-464 / :667-681
-//   4. x continuum, Gaussian log-likelihood terms, nansum, wave+LDS reduce
-//                                                                   hires_fitter.py:292-294
-// and a tiny second kernel that adds the per-tile partials in fixed order (deterministic: no
-// float atomics, so a sharded batch equals the unsharded one bit for bit).
+// Per call, on the caller's stream:
+//   mcalf_sample_kernel  one wave per live point s: decode p_s (optionally from a unit-cube row), the
+//                        (component,line) records, the LSF taps                hires_fitter.py:412-431,357-364,454-459
+//   mcalf_fused_kernel   one workgroup per (live point s, pixel tile T):
+//     1. tau(pixel) = sum_cl K_cl H(u_cl(pixel), a_cl): per line a node pass (far wings at 8 nodes per 64-pixel
+//        segment, interpolated once per sample) and per-pixel evaluation of the rest; flux = exp(-tau) into an
+//        LDS tile with +-n halo                                               hires_fitter.py:365,377,430-442
+//     2. sliding-window Gaussian LSF from LDS (periodic / zero-pad)           hires_fitter.py:452-464 / :667-681
+//     3. x continuum, Gaussian log-likelihood terms, nansum, wave + LDS reduce   hires_fitter.py:292-294
+//   mcalf_finalize_kernel  only when a spectrum needs several tiles: adds the per-tile partials in fixed order
+//                        (no float atomics anywhere, so a sharded batch equals the unsharded one bit for bit).
 //
 // The C ABI is declared in include/mcalf_hip.h.  There is no CPU fallback: every entry point
 // fails with MCALF_ERR_NODEVICE when no gfx950 device is present.
