@@ -258,7 +258,7 @@ def main():
                               "frac": alg_flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                               "algorithmic_flops_per_launch": alg_flops},
         }
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:          # the CPU baseline is an N=1 figure (rank 0 only)
             vals, dt, done = cpu_baseline(kw, P_host, args.cpu_seconds)
             k = len(vals)
             evals = sum(float(nc[i % batch]) for i in range(done)) * npix
