@@ -52,7 +52,7 @@ def cpu_baseline(kw, P, budget_s):
                           fitrange=kw["fitrange"])
     oracle.lnlhood_worker(prob, P[0])          # warm
     vals, t0, done = [], time.perf_counter(), 0
-    while time.perf_counter() - t0 < budget_s:   # cycle over the batch until the time budget is spent
+    while time.perf_counter() - t0 < budget_s or done < (len(P) if budget_s <= 0 else 0):   # cycle over the batch until the time budget is spent (budget 0: every row once)
         row = P[done % len(P)]
         v = oracle.lnlhood_worker(prob, row)
         if done < len(P):
@@ -289,6 +289,10 @@ def main():
                     "value": reps * float(nc[: len(rows)].sum()) * npix / dtc, "unit": "evals/s", "cores": nthr, "kind": "port",
                     "sample": f"{reps} x {len(rows)} rows, oracle/c/mcalf_oracle.c (gcc -O2 -fopenmp), {dtc:.1f} s",
                     "max_abs_dlogL_vs_gpu": float(np.abs(cvals - logL_dev[: len(rows)]).max())}
+    if out is not None and world > 1 and args.cpu_seconds > 0:
+        # N>1: no CPU timing, only a parity spot check of rank 0's first rows against the oracle
+        vals, _, _ = cpu_baseline(kw, P_host[:8], 0.0)
+        out["parity"] = {"max_abs_dlogL_vs_oracle": float(np.abs(vals - logL_dev[:len(vals)]).max()), "rows": len(vals)}
     if out is not None and gather_check is not None:
         out["gather_check"] = gather_check
     fit.close()
