@@ -163,6 +163,9 @@ int mcalf_loglike_cube_batch_device(mcalf_ctx* ctx, const double* dcube, int64_t
 /* Diagnostic: out[i] = H(x[i], y[i]) = Re w(x + i y) evaluated by the device Voigt function
  * (host pointers).  device = -1 for the current device. */
 int mcalf_voigt_hjerting(const double* x, const double* y, int64_t n, double* out, int32_t device);
+/* Same with the arithmetic an interpolation NODE gets: between x_c (6.2 for K = 1) and 8 the zone-1 wing
+ * polynomial with exp(-x^2) dropped, instead of the core table a directly evaluated pixel uses there. */
+int mcalf_voigt_hjerting_nodes(const double* x, const double* y, int64_t n, double* out, int32_t device);
 
 #ifdef __cplusplus
 }

@@ -88,6 +88,7 @@ SYMBOLS = {
     "mcalf_loglike_cube_batch": (C.c_int, [_CTX, _PD, C.c_int64, _PD, _PD]),
     "mcalf_loglike_cube_batch_device": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcalf_voigt_hjerting": (C.c_int, [_PD, _PD, C.c_int64, _PD, C.c_int32]),
+    "mcalf_voigt_hjerting_nodes": (C.c_int, [_PD, _PD, C.c_int64, _PD, C.c_int32]),
 }
 
 _lib = None

@@ -194,7 +194,9 @@ __device__ __forceinline__ double pow10_fast(double x) {
 
 // Record per (component,line): [A, B, x2c, y, K, Kyt, Kgen, uthr]   (general-path lines: [A, B, y, 0, 0, 0, K, 0])
 //   u = nu*A - B;  tau += K H(u, y);  Kyt = K y / sqrt(pi) scales the wing polynomials;
-//   x2c: below it the core table (with exp(-x^2)) is used;  Kgen != 0 -> general path (eval_general_lines);
+//   x2c = x_c^2: beyond it exp(-x^2) is below 2e-17 in optical depth, so the line is pure wing there (the
+//        interpolation threshold never lies inside it; nodes between x_c and 8 use the zone-1 polynomial);
+//   Kgen != 0 -> general path (eval_general_lines);
 //   uthr: a 64-pixel segment whose pixels all have |u| >= uthr is evaluated at 8 nodes and interpolated.
 __device__ inline void build_line_record(double* rec, double logN, double z, double b_kms, const LineDev& ln,
                                          double dnu_seg) {
@@ -324,15 +326,15 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
             P = cF[VT_FDEG];
 #pragma unroll
             for (int k = VT_FDEG - 1; k >= 0; --k) P = fma(P, t, cF[k]);
-        } else if (x2 >= x2c) {                       // exp(-u^2) gone: polynomial in 1/u^2
+        } else if (x2 >= kX2Wing) {                   // 8 <= |u| < 16: polynomial in 1/u^2 (broadcast reads)
             t = fast_rcp(x2);
-            const bool z0 = x2 >= kX2Wing;
-            const double sv = z0 ? t : fma(t, VT_Z1_A, VT_Z1_B);
-            const double* cw = tab + (z0 ? kZ0Lds : VT_Z1_OFF);
+            const double* cw = tab + kZ0Lds;
             P = cw[VT_WDEG];
 #pragma unroll
-            for (int k = VT_WDEG - 1; k >= 0; --k) P = fma(P, sv, cw[k]);
-        } else {                                      // core table (per-lane LDS gather)
+            for (int k = VT_WDEG - 1; k >= 0; --k) P = fma(P, t, cw[k]);
+        } else {                                      // |u| < 8: core table (per-lane LDS gather).  It is valid up to 8, so the
+                                                      // pixels between x_c and 8 come here too instead of splitting the wave over
+                                                      // a third path (zone 1 serves the interpolation nodes only)
             const double x = fabs(u);
             int jx = (int)(x * 4.0);
             jx = min(max(jx, 0), VT_NINT - 1);
@@ -779,9 +781,10 @@ __global__ void mcalf_finalize_kernel(const double* partial, double* out, long b
     out[s] = finalize_value(mode, sum, cnt, asymm != 0, c4, c5, veto4, veto5);
 }
 
-__global__ void mcalf_hjert_kernel(const double* x, const double* y, long n, double* out, const double* tabs) {
+__global__ void mcalf_hjert_kernel(const double* x, const double* y, long n, double* out, const double* tabs,
+                                   int node_form) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = hjert_folded(x[i], y[i], tabs);
+    if (i < n) out[i] = hjert_folded(x[i], y[i], tabs, node_form != 0);
 }
 
 __global__ void mcalf_scale_cube_kernel(const double* lo, const double* hi, const double* cube, long total,
@@ -1363,7 +1366,7 @@ extern "C" int mcalf_scale_cube_batch(mcalf_ctx* ctx, const double* lo, const do
     return MCALF_OK;
 }
 
-extern "C" int mcalf_voigt_hjerting(const double* x, const double* y, int64_t n, double* out, int32_t device) {
+static int hjerting_impl(const double* x, const double* y, int64_t n, double* out, int32_t device, int node_form) {
     if (n < 0 || (n > 0 && (!x || !y || !out))) return set_err(nullptr, MCALF_ERR_INVALID, "bad arguments");
     if (n == 0) return MCALF_OK;
     int dev = 0;
@@ -1381,7 +1384,7 @@ extern "C" int mcalf_voigt_hjerting(const double* x, const double* y, int64_t n,
         if (e == hipSuccess) e = hipMemcpy(dy, y, nb, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(mcalf_hjert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dx, dy, (long)n,
-                               dout, dtabs);
+                               dout, dtabs, node_form);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpy(out, dout, nb, hipMemcpyDeviceToHost);
@@ -1390,6 +1393,14 @@ extern "C" int mcalf_voigt_hjerting(const double* x, const double* y, int64_t n,
     (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
     if (dtabs) (void)hipFree(dtabs);
     return rc;
+}
+
+extern "C" int mcalf_voigt_hjerting(const double* x, const double* y, int64_t n, double* out, int32_t device) {
+    return hjerting_impl(x, y, n, out, device, 0);
+}
+
+extern "C" int mcalf_voigt_hjerting_nodes(const double* x, const double* y, int64_t n, double* out, int32_t device) {
+    return hjerting_impl(x, y, n, out, device, 1);
 }
 
 #ifdef MCALF_STAMPS

@@ -148,13 +148,15 @@ __device__ __noinline__ double hjert_general(double x, double y) {
     return 2.0 * exp((ay - x) * (x + ay)) * cos(2.0 * x * ay) - hjert_upper(x, ay);
 }
 
-// Full H(x, y) with exactly the kernel's arithmetic for a line of optical-depth scale K = 1
-// (diagnostic entry).  T is the [VT_NY][VT_NTOT] table in global memory.
-__device__ inline double hjert_folded(double x, double y, const double* __restrict__ T) {
+// Full H(x, y) with exactly the kernel's arithmetic for a line of optical-depth scale K = 1 (diagnostic
+// entries).  T is the [VT_NY][VT_NTOT] table in global memory.  node_form = false: what a directly evaluated
+// pixel gets (core table for every |x| < 8); true: what an interpolation node gets (zone 1, exp(-x^2) dropped,
+// between x_c and 8).
+__device__ inline double hjert_folded(double x, double y, const double* __restrict__ T, bool node_form) {
     x = fabs(x);
     if (!(y <= kYFastMax) || !(y >= 0.0)) return hjert_general(x, y);
     const double x2 = x * x;
-    const double x2c = core_limit_x2(1.0);
+    const double x2c = node_form ? core_limit_x2(1.0) : kX2Wing;
     double Tn[VT_NY];
     if (x2 >= x2c) {
         const double t = fast_rcp(x2);

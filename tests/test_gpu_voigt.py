@@ -12,13 +12,15 @@ from mcalf_amd import _lib
 pytestmark = pytest.mark.gpu
 
 
-def hjert_gpu(x, y):
+def hjert_gpu(x, y, nodes=False):
+    """nodes=False: the arithmetic of a directly evaluated pixel (core table for every |x| < 8);
+    nodes=True: that of an interpolation node (zone-1 wing polynomial between x_c and 8)."""
     x = np.ascontiguousarray(np.broadcast_to(x, np.broadcast(x, y).shape), dtype=float).ravel()
     y = np.ascontiguousarray(np.broadcast_to(y, x.shape), dtype=float).ravel()
     out = np.empty_like(x)
     pd = C.POINTER(C.c_double)
-    _lib.check(_lib.load().mcalf_voigt_hjerting(x.ctypes.data_as(pd), y.ctypes.data_as(pd), x.size,
-                                                out.ctypes.data_as(pd), -1))
+    fn = _lib.load().mcalf_voigt_hjerting_nodes if nodes else _lib.load().mcalf_voigt_hjerting
+    _lib.check(fn(x.ctypes.data_as(pd), y.ctypes.data_as(pd), x.size, out.ctypes.data_as(pd), -1))
     return out
 
 
@@ -32,10 +34,11 @@ def test_dense_grid_vs_scipy_fast_path():
     u = np.concatenate([np.linspace(0, 8, 4001), np.linspace(8, 40, 2001), 10 ** rng.uniform(1, 3.5, 4000),
                         -rng.uniform(0, 30, 500)])
     for a in [1e-7, 1.8e-5, 1e-4, 3.3e-4, 1.2e-3, 2 ** -8]:
-        got = hjert_gpu(u, a)
         ref = wofz(u + 1j * a).real
-        # scipy itself is ~2e-14; the kernel drops exp(-x^2) once it is < 2e-17 (K = 1)
-        assert (np.abs(got - ref) / (3e-17 + 6e-14 * ref)).max() < 1, a
+        for nodes in (False, True):
+            got = hjert_gpu(u, a, nodes=nodes)
+            # scipy itself is ~2e-14; the node form drops exp(-x^2) once it is < 2e-17 (K = 1)
+            assert (np.abs(got - ref) / (3e-17 + 6e-14 * ref)).max() < 1, (a, nodes)
 
 
 def test_dense_grid_vs_scipy_general_path():
@@ -52,11 +55,12 @@ def test_spot_points_vs_mpmath():
     xs = np.concatenate([rng.uniform(0, 8, 120), rng.uniform(8, 16, 40), 10 ** rng.uniform(1.2, 3.5, 40),
                          [0.0, 7.9999999, 8.0, 8.0000001]])
     for a in [1e-9, 1.8e-5, 1.2e-3, 2 ** -8, 0.00391, 0.02, 1.5]:
-        got = hjert_gpu(xs, a)
         ex = np.array([float(_mp_H(x, a)) for x in xs])
         rtol = 5e-15 if a <= 2 ** -8 else 2e-14
-        err = np.abs(got - ex) / (3e-17 + rtol * ex)
-        assert err.max() < 1, (a, xs[err.argmax()], err.max())
+        for nodes in (False, True):
+            got = hjert_gpu(xs, a, nodes=nodes)
+            err = np.abs(got - ex) / (3e-17 + rtol * ex)
+            assert err.max() < 1, (a, nodes, xs[err.argmax()], err.max())
 
 
 def test_limits():

@@ -79,3 +79,14 @@ try:
         print("setup: %-24s mean %7.0f  round1 %7.0f  round2 %7.0f cycles" % (nm[k], d.mean(), d[first].mean(), d[~first].mean()))
 except AttributeError:
     pass
+
+try:
+    acc = (C.c_ulonglong * (n * 8))()
+    lib.mcalf_diag_read_acc.argtypes = [C.c_void_p, C.c_int]
+    lib.mcalf_diag_read_acc(acc, n * 8)
+    a = np.array(acc, dtype=np.uint64).reshape(n, 2, 4).astype(np.int64)
+    for w in range(2):
+        print("wave %d loop accounting [cycles]: fold %6.0f  barrier wait %6.0f  node pass %6.0f  direct %6.0f   (sum %6.0f)"
+              % (w, a[:, w, 0].mean(), a[:, w, 1].mean(), a[:, w, 2].mean(), a[:, w, 3].mean(), a[:, w].sum(axis=1).mean()))
+except AttributeError:
+    pass
