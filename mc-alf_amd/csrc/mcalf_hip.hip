@@ -100,6 +100,7 @@ struct KArgs {
     int npix, ndim, ntiles, tile, n_cap, ncl_cap;
     int nlines, ncompmax, nfill, startind, endind, freespecres, freecont;
     int targonly, mode, jax_half, onecomp_fill, asymm;
+    int selfhalo;           // 1: single-tile spectrum whose halo entries are copies of the tile's own pixels (see fused kernel)
     double specres_fixed, contval_fixed, velstep, log2pi;
     double dnu_seg;         // largest |nu(first) - nu(last)| over the 64-pixel segments
     double veto4, veto5;    // asymmetric veto: allowed counts of resid > 4 / > 5 (threshold + grace)
@@ -503,7 +504,7 @@ __device__ __forceinline__ void eval_general_lines(const double* __restrict__ sR
 #ifndef MCALF_MIN_WAVES
 #define MCALF_MIN_WAVES 4
 #endif
-template <bool kZeroPad>
+template <bool kZeroPad, bool kSelfHalo>
 __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {
     extern __shared__ __align__(16) double smem[];
     double* sTab = smem;                                   // 2 x kLinesPerSync folded tables
@@ -535,9 +536,17 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
 
     // The tile always carries the full provisioned halo n_cap (so that its 64-pixel segments are the
     // same for every sample); a sample with a shorter kernel simply starts `shift` entries in.
+    //
+    // Self-halo mode (a spectrum that fits ONE tile, the usual case): the periodic halo of the convolution
+    // consists of copies of the tile's own pixels, so only the npix real pixels are evaluated -- thread index =
+    // pixel index, every 64-pixel segment starts at a multiple of 64 and none crosses the seam -- and each
+    // flux value is stored at its body position and, near the ends, at its halo position too.  (With the halo
+    // evaluated as part of the tile, the segments that contain the seam cannot be interpolated; the three
+    // waves that own them then hold every barrier of the component loop back.)
+    constexpr bool selfHalo = kSelfHalo;               // (a.selfhalo chooses the instantiation on the host)
     const int t0 = tileIdx * a.tile;
     const int tlen = min(a.tile, a.npix - t0);
-    const int ext0 = t0 - a.n_cap;
+    const int ext0 = selfHalo ? 0 : t0 - a.n_cap;
     const int extCount = tlen + 2 * a.n_cap;
     double nu[kPpt], tau[kPpt];
 #pragma unroll
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         const int idx = tid + j * kBlock;
         int e = ext0 + idx;
         bool zero = false;
-        if (e < 0 || e >= a.npix) {
+        if (!selfHalo && (e < 0 || e >= a.npix)) {          // (self-halo: nu is padded to the thread count)
             if (kZeroPad) { zero = true; e = 0; }            // jnp.convolve 'same' zero padding (:674)
             else { e %= a.npix; if (e < 0) e += a.npix; }    // astropy boundary='wrap'
         }
@@ -558,7 +567,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     if (kFarInterp) {
         const int wv = tid >> 6, ln = tid & 63;
         int e = ext0 + 64 * wv + kBlock * (ln >> 3) + VT_INTERP_NODES[ln & 7];
-        if (e < 0 || e >= a.npix) { e %= a.npix; if (e < 0) e += a.npix; }      // such segments are never interpolated
+        if (!selfHalo && (e < 0 || e >= a.npix)) { e %= a.npix; if (e < 0) e += a.npix; }   // such segments are never interpolated
         nuNode = a.nu[e];
         tileMask = a.segok[tileIdx];                                           // bit m = segment m = wave + 8 j
     }
@@ -672,8 +681,19 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             for (int k = 0; k < VT_INODES; ++k) add = fma(wrow[k], sFar[8 * j + k], add);
             tj += add;
         }
-        const int pos = tid + j * kBlock - shift;
-        if (pos >= 0 && pos < extTight) sF[tile_pos(pos)] = exp_neg(tj);    // :377 (product of exp == exp of sum)
+        const double fl = exp_neg(tj);                 // :377 (product of exp == exp of sum)
+        if (selfHalo) {
+            const int p = tid + j * kBlock;            // pixel index; tile layout [n halo | npix body | n halo]
+            if (p < a.npix) {
+                sF[tile_pos(p + n)] = fl;
+                // periodic copies (astropy boundary='wrap'); the JAX path pads with zeros instead (:674)
+                if (p < n) sF[tile_pos(p + n + a.npix)] = kZeroPad ? 0.0 : fl;
+                if (p >= a.npix - n) sF[tile_pos(p + n - a.npix)] = kZeroPad ? 0.0 : fl;
+            }
+        } else {
+            const int pos = tid + j * kBlock - shift;
+            if (pos >= 0 && pos < extTight) sF[tile_pos(pos)] = fl;
+        }
         __builtin_amdgcn_sched_barrier(0);             // keep the 8 broadcast reads of one j from piling up
     }
     if (tid < kTileSlack) sF[tile_pos(extTight + tid)] = 0.0;
@@ -825,7 +845,7 @@ struct mcalf_ctx {
     int asymm = 0;
     double veto4 = 0, veto5 = 0;
     // geometry
-    int n_cap = 0, tile = 0, ntiles = 0, ncl_cap = 0, jax_half = 0;
+    int n_cap = 0, tile = 0, ntiles = 0, ncl_cap = 0, jax_half = 0, selfhalo = 0;
     size_t lds_bytes = 0;
     // device buffers
     double *d_nu = nullptr, *d_obj = nullptr, *d_ispec2 = nullptr, *d_lgis = nullptr, *d_err = nullptr, *d_tabs = nullptr;
@@ -996,14 +1016,47 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     ctx->tile = (int)tile;
     ctx->ntiles = (int)ntiles;
     ctx->lds_bytes = (fixed_doubles + (size_t)tile_doubles((int)tile + 2 * ctx->n_cap)) * sizeof(double);
+    ctx->selfhalo = (ntiles == 1 && ctx->n_cap < ctx->npix) ? 1 : 0;
 
     // spectrum arrays (float64 host arithmetic identical to the reference's numpy expressions)
-    std::vector<double> nu(ctx->npix), is2(ctx->npix), lg(ctx->npix);
+    // Self-halo contexts index nu by thread (0 .. kExtMax-1): the entries past the spectrum are VIRTUAL pixels.
+    // Up to the next multiple of 64 they continue the wavelength grid when it is recognisably linear or
+    // logarithmic over its last 64 pixels (so that the last, partial segment can be interpolated like the
+    // others; the virtual pixels' own results are never stored); beyond that they repeat the last value.
+    const long nu_len = ctx->selfhalo ? (long)kExtMax : ctx->npix;
+    std::vector<double> nu(nu_len), is2(ctx->npix), lg(ctx->npix);
     for (long i = 0; i < ctx->npix; ++i) {
         const double wave_cm = sp->wl[i] / 1e8;            // :376
         nu[i] = kCcgs / wave_cm;                           // :362 at zp1 = 1
         is2[i] = 1.0 / (sp->err[i] * sp->err[i]);          // :292
         lg[i] = std::log(is2[i]);                          // :294
+    }
+    if (ctx->selfhalo) {
+        const long n = ctx->npix, upto = std::min<long>(nu_len, (n + 63) & ~63L);
+        int kind = 0;                                      // 1 linear, 2 logarithmic
+        if (n >= 66) {
+            const double d = sp->wl[n - 1] - sp->wl[n - 2], r = sp->wl[n - 1] / sp->wl[n - 2];
+            bool lin = true, lg_ = true;
+            for (long i = n - 64; i < n - 1; ++i) {
+                if (!(std::fabs((sp->wl[i + 1] - sp->wl[i]) - d) <= 1e-9 * std::fabs(d))) lin = false;
+                if (!(std::fabs(sp->wl[i + 1] / sp->wl[i] - r) <= 1e-9 * std::fabs(r - 1.0))) lg_ = false;
+            }
+            kind = lin ? 1 : (lg_ ? 2 : 0);
+        }
+        // the common step from the pixels 64 apart (averages the grid's own rounding noise)
+        const double step = kind == 1 ? (sp->wl[n - 1] - sp->wl[n - 65]) / 64.0
+                          : kind == 2 ? std::exp(std::log(sp->wl[n - 1] / sp->wl[n - 65]) / 64.0) : 0.0;
+        for (long i = n; i < nu_len; ++i) {
+            if (kind != 0 && i < upto) {
+                const double m = (double)(i - (n - 1));
+                const double wl = kind == 1 ? sp->wl[n - 1] + m * step : sp->wl[n - 1] * std::pow(step, m);
+                nu[i] = kCcgs / (wl / 1e8);
+            } else {
+                // past the last (partial) segment nothing is ever stored: nu = 0 puts these lanes at u = -nu0/dnu,
+                // thousands of Doppler widths away from every line, so their segments go the cheap node-only way
+                nu[i] = (i >= upto) ? 0.0 : nu[i - 1];
+            }
+        }
     }
     std::vector<LineDev> lines(ctx->nlines + 1);
     for (int l = 0; l <= ctx->nlines; ++l) {
@@ -1015,7 +1068,7 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     }
     const size_t nb = (size_t)ctx->npix * sizeof(double);
     const size_t nbp = nb + 8 * sizeof(double);          // the epilogue reads 8 pixels per thread without a bounds test
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_nu, nb));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_nu, (size_t)nu_len * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_obj, nbp));
     HIP_TRY(ctx, hipMemset(ctx->d_obj, 0, nbp));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ispec2, nbp));
@@ -1025,7 +1078,7 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_err, nbp));
     HIP_TRY(ctx, hipMemset(ctx->d_err, 0, nbp));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_lines, lines.size() * sizeof(LineDev)));
-    HIP_TRY(ctx, hipMemcpy(ctx->d_nu, nu.data(), nb, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_nu, nu.data(), (size_t)nu_len * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_obj, sp->flux, nb, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_ispec2, is2.data(), nb, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_lgis, lg.data(), nb, hipMemcpyHostToDevice));
@@ -1043,12 +1096,21 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     for (int t = 0; t < ctx->ntiles; ++t) {
         const long t0 = (long)t * ctx->tile;
         const long tlen = std::min<long>(ctx->tile, ctx->npix - t0);
-        const long ext0 = t0 - ctx->n_cap, extCount = tlen + 2L * ctx->n_cap;
+        const long ext0 = ctx->selfhalo ? 0 : t0 - ctx->n_cap, extCount = tlen + 2L * ctx->n_cap;
         for (int m = 0; m < 64; ++m) {
             const long i0 = 64L * m;
-            if (i0 + 64 > extCount) continue;
             const long e0 = ext0 + i0;
-            if (e0 < 0 || e0 + 63 >= ctx->npix) continue;
+            if (ctx->selfhalo) {
+                if (e0 + 63 >= nu_len) continue;
+                if (e0 >= ((ctx->npix + 63) & ~63L)) {          // wholly virtual (nu = 0): nothing to get wrong
+                    segok[t] |= 1ULL << m;
+                    continue;
+                }
+                // otherwise: real pixels, the last segment completed by the virtual continuation of the grid
+            } else {
+                if (i0 + 64 > extCount) continue;
+                if (e0 < 0 || e0 + 63 >= ctx->npix) continue;
+            }
             bool ok = true;
             const double dir = nu[e0 + 63] - nu[e0];
             for (int i = 0; i < 64 && ok; ++i) {
@@ -1069,10 +1131,12 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_wtab, sizeof(VT_INTERP_W_HOST)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_wtab, VT_INTERP_W_HOST, sizeof(VT_INTERP_W_HOST), hipMemcpyHostToDevice));
     // more than 64 KiB of dynamic LDS needs the attribute (2 workgroups x 78 KiB fit the 160 KiB of a CU)
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&mcalf_fused_kernel<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&mcalf_fused_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    const void* kernels[] = {reinterpret_cast<const void*>(&mcalf_fused_kernel<false, false>),
+                             reinterpret_cast<const void*>(&mcalf_fused_kernel<false, true>),
+                             reinterpret_cast<const void*>(&mcalf_fused_kernel<true, false>),
+                             reinterpret_cast<const void*>(&mcalf_fused_kernel<true, true>)};
+    for (const void* k : kernels)
+        HIP_TRY(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     return MCALF_OK;
 }
@@ -1157,6 +1221,7 @@ static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int
     a.startind = ctx->startind; a.endind = ctx->endind;
     a.freespecres = ctx->freespecres; a.freecont = ctx->freecont;
     a.targonly = targonly; a.mode = mode; a.jax_half = ctx->jax_half; a.onecomp_fill = onecomp_fill;
+    a.selfhalo = ctx->selfhalo;
     a.specres_fixed = ctx->specres_fixed; a.contval_fixed = ctx->contval_fixed; a.velstep = ctx->velstep;
     a.log2pi = std::log(2.0 * M_PI);
     a.prior_lo = from_cube ? ctx->d_prior : nullptr;
@@ -1171,10 +1236,11 @@ static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int
     HIP_TRY(ctx, hipGetLastError());
     const bool timed = ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used], stream));
-    if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX)
-        hipLaunchKernelGGL(mcalf_fused_kernel<true>, grid, block, ctx->lds_bytes, stream, a);
-    else
-        hipLaunchKernelGGL(mcalf_fused_kernel<false>, grid, block, ctx->lds_bytes, stream, a);
+    const bool jaxmode = ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX;
+    if (jaxmode && ctx->selfhalo) hipLaunchKernelGGL((mcalf_fused_kernel<true, true>), grid, block, ctx->lds_bytes, stream, a);
+    else if (jaxmode) hipLaunchKernelGGL((mcalf_fused_kernel<true, false>), grid, block, ctx->lds_bytes, stream, a);
+    else if (ctx->selfhalo) hipLaunchKernelGGL((mcalf_fused_kernel<false, true>), grid, block, ctx->lds_bytes, stream, a);
+    else hipLaunchKernelGGL((mcalf_fused_kernel<false, false>), grid, block, ctx->lds_bytes, stream, a);
     HIP_TRY(ctx, hipGetLastError());
     if (timed) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], stream));

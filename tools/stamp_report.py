@@ -81,11 +81,11 @@ except AttributeError:
     pass
 
 try:
-    acc = (C.c_ulonglong * (n * 8))()
+    acc = (C.c_ulonglong * (n * 32))()
     lib.mcalf_diag_read_acc.argtypes = [C.c_void_p, C.c_int]
-    lib.mcalf_diag_read_acc(acc, n * 8)
-    a = np.array(acc, dtype=np.uint64).reshape(n, 2, 4).astype(np.int64)
-    for w in range(2):
+    lib.mcalf_diag_read_acc(acc, n * 32)
+    a = np.array(acc, dtype=np.uint64).reshape(n, 8, 4).astype(np.int64)
+    for w in range(8):
         print("wave %d loop accounting [cycles]: fold %6.0f  barrier wait %6.0f  node pass %6.0f  direct %6.0f   (sum %6.0f)"
               % (w, a[:, w, 0].mean(), a[:, w, 1].mean(), a[:, w, 2].mean(), a[:, w, 3].mean(), a[:, w].sum(axis=1).mean()))
 except AttributeError:
