@@ -341,6 +341,118 @@ def jax_loglike_f64(prob: Problem, p) -> float:
 
 
 # ----------------------------------------------------------------------------------
+# The JAX path AS SHIPPED: float32 arithmetic and voigt_jax.hjert (Algorithm 916 / asymptotic form).
+# Informational only: float32 loses ~1e-2 in u to cancellation, so this is not a
+# parity target; tests/test_oracle_golden.py records how far the reference's own two paths are apart.
+# numpy float32 arrays keep every intermediate in float32 (XLA may fuse / contract differently, at the
+# 6e-8 level -- three orders of magnitude below the effect being shown).
+# ----------------------------------------------------------------------------------
+
+_AN = np.arange(1, 28) * 0.5                                   # voigt_jax.py:60-66
+_SIG1_W = np.array([7.78800786e-01, 3.67879450e-01, 1.05399221e-01, 1.83156393e-02, 1.93045416e-03,
+                    1.23409802e-04, 4.78511765e-06, 1.12535176e-07])    # :77-86
+_ERFCX_P = [5.92470169e-5, 1.61224554e-4, -3.46481771e-4, -1.39681227e-3, 1.20588380e-3, 8.69014394e-3,
+            -8.01387429e-3, -5.42122945e-2, 1.64048523e-1, -1.66031078e-1, -9.27637145e-2, 2.76978403e-1]
+
+
+def jax_erfcx(x, dt=np.float32):
+    """voigt_jax.py:5-57 (Shepherd & Laframboise 1981)."""
+    x = np.asarray(x, dtype=dt)
+    one, two, half = dt(1.0), dt(2.0), dt(0.5)
+    a = np.abs(x)
+    b = (a - two) / (a + two)
+    q = (-a * b - two * (b + one) + a) / (a + two) + b
+    pp = dt(_ERFCX_P[0])
+    for c in _ERFCX_P[1:]:
+        pp = pp * q + dt(c)
+    q = (pp + one) / (one + two * a)
+    d = (pp + one) - q * (one + two * a)
+    f = half * d / (a + half) + q
+    with np.errstate(over="ignore"):
+        return np.where(x >= 0, f, two * np.exp(x * x) - f).astype(dt)
+
+
+def jax_hjert(x, a, dt=np.float32):
+    """voigt_jax.hjert (voigt_jax.py:89-127): Algorithm 916 with a = 0.5 inside r^2 < 111, the
+    three-term asymptotic series outside; x array, a scalar."""
+    x = np.asarray(x, dtype=dt)
+    a = dt(a)
+    pi = dt(np.pi)
+    with np.errstate(all="ignore"):
+        xy = x * a
+        exx = np.exp(-x * x)
+        sinc = np.where(xy == 0, dt(1.0), np.sin(xy) / np.where(xy == 0, dt(1.0), xy)).astype(dt)   # jnp.sinc(xy/pi)
+        f = exx * (jax_erfcx(a, dt) * np.cos(dt(2.0) * xy) + x * np.sin(xy) / pi * sinc)
+        y2 = a * a
+        an = _AN.astype(dt)
+        a2n2 = (an * an).astype(dt)
+        s23 = ((np.exp(-((an[None, :] + x[:, None]) ** 2)) + np.exp(-((an[None, :] - x[:, None]) ** 2)))
+               / (a2n2[None, :] + y2)).sum(axis=1, dtype=dt)
+        s1 = exx * (_SIG1_W.astype(dt) / (a2n2[:8] + y2)).sum(dtype=dt)
+        small = f + a / pi * (-np.cos(dt(2.0) * xy) * s1 + dt(0.5) * s23)
+        cdt = np.complex64 if dt == np.float32 else np.complex128
+        z = (x + 1j * a).astype(cdt)
+        aa = (1.0 / (2.0 * z * z)).astype(cdt)
+        q = ((1j) / (z * cdt(np.sqrt(np.pi))) * (1.0 + aa * (1.0 + aa * (3.0 + aa * 15.0)))).astype(cdt)
+        r2 = x * x + a * a
+        return np.where(r2 < dt(111.0), small, q.real.astype(dt)).astype(dt)
+
+
+def jax_reconstruct_spec_f32(prob: Problem, p, dt=np.float32) -> np.ndarray:
+    """hires_fitter.py:521-683 with every captured array and the parameter vector in `dt`."""
+    p = np.asarray(p, dtype=dt)
+    wl = prob.wl.astype(dt)
+    R = p[0] if prob.freespecres else dt(float(prob.specres[0]))
+    cont = (p[1] if prob.freespecres else p[0]) if prob.freecont else dt(float(prob.contval[0]))
+    nc = int(np.floor(p[prob.startind]))
+    s = prob.startind
+
+    def tau_of(N, z, b, wrest, f, gam):                         # :576-599
+        with np.errstate(all="ignore"):
+            cold = dt(10.0) ** N
+            zp1 = z + dt(1.0)
+            w_cm = wl / dt(1e8)
+            wrest_cm = dt(wrest) / dt(1e8)
+            nujk = dt(CCGS) / wrest_cm
+            dnu = (b * dt(1e5)) / wrest_cm
+            av = dt(gam) / (dt(4.0) * dt(np.pi) * dnu)
+            uv = ((dt(CCGS) / (w_cm / zp1)) - nujk) / dnu
+            cne = dt(0.014971475) * cold * dt(f)
+            return (cne * jax_hjert(uv, av, dt) / dnu).astype(dt)
+
+    tau = np.zeros_like(wl)
+    for c in range(min(nc, prob.ncompmax)):
+        N, z, b = p[1 + 3 * c + s: 1 + 3 * c + 3 + s]
+        comp = np.zeros_like(wl)
+        for (wrest, f, gam) in prob.lines:
+            comp = (comp + tau_of(N, z, b, wrest, f, gam)).astype(dt)
+        tau = tau + comp
+    wrest, f, gam = prob.linefill
+    for k in range(prob.nfill):
+        N, z, b = p[3 * k + prob.endind: 3 * k + 3 + prob.endind]
+        tau = (tau + tau_of(N, z, b, wrest, f, gam)).astype(dt)
+    model = np.exp(-tau)
+    half = jax_half_size(prob)
+    sigma = (R / dt(2.354820)) / dt(prob.velstep)
+    kx = np.arange(-half, half + 1).astype(dt)
+    ker = np.exp(-kx ** 2 / (dt(2.0) * sigma ** 2))
+    ker = (ker / ker.sum(dtype=dt)).astype(dt)
+    conv = np.convolve(model, ker, mode="same").astype(dt)
+    idx = np.arange(model.size)
+    edge = (idx < half) | (idx >= model.size - half)
+    return (np.where(edge, model, conv) * cont).astype(dt)
+
+
+def jax_loglike_f32(prob: Problem, p, dt=np.float32) -> float:
+    """hires_fitter.py:685-693 in `dt`."""
+    model = jax_reconstruct_spec_f32(prob, p, dt)
+    err = prob.err.astype(dt)
+    obj = prob.flux.astype(dt)
+    ispec2 = dt(1.0) / (err ** 2)
+    return float(dt(-0.5) * np.nansum(ispec2 * (obj - model) ** 2 - np.log(ispec2) + np.log(dt(2.0) * dt(np.pi)), dtype=dt))
+
+
+# ----------------------------------------------------------------------------------
 # Analysis helpers ("next" rows, SURVEY.md section 8f-4)
 # ----------------------------------------------------------------------------------
 

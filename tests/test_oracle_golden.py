@@ -101,3 +101,26 @@ def test_edge_cases_numpy_path():
     flux[100] = np.nan
     prob2 = o.Problem(d[:, 0], flux, d[:, 2], o.CIV_LINES, (1, 1), specres=[8.0])
     assert np.isfinite(o.lnlhood_worker(prob2, p))
+
+
+def test_distance_between_the_references_own_two_paths_is_reproduced():
+    """Informational pin: the JAX path as shipped -- float32, voigt_jax.hjert -- restated in
+    numpy lands where the survey's probe found it on the multicomponent fixture at the truth parameters
+    (max |dflux| 2.1e-3, max rel 5.6e-3, dlogL -0.61), and the same algorithm in float64 within 1e-8 / -5.7e-6.
+    This is why parity is asserted against the float64 numpy path only."""
+    from mcalf_amd import workloads
+    d = np.loadtxt(os.path.join(GOLD, "civ_mock_spec_multicomp.txt"))
+    prob = o.Problem(d[:, 0], d[:, 1], d[:, 2], o.CIV_LINES, (10, 10), specres=[8.0])
+    p = workloads.truth_vector(10)
+    m_np, l_np = o.reconstruct_spec(prob, p), o.lnlhood_worker(prob, p)
+    m32, l32 = o.jax_reconstruct_spec_f32(prob, p), o.jax_loglike_f32(prob, p)
+    assert 1.5e-3 < np.abs(m32 - m_np).max() < 3e-3
+    assert 4e-3 < (np.abs(m32 - m_np) / m_np).max() < 8e-3
+    assert -0.8 < l32 - l_np < -0.45
+    m64, l64 = o.jax_reconstruct_spec_f32(prob, p, np.float64), o.jax_loglike_f32(prob, p, np.float64)
+    assert np.abs(m64 - m_np).max() < 5e-8 and -1e-5 < l64 - l_np < -1e-6
+    # the Voigt function of that path: ~1e-6 relative from its three-term asymptotic branch
+    x = np.linspace(0, 30, 1501)
+    from scipy.special import wofz
+    rel = np.abs(o.jax_hjert(x, 1.2e-3, np.float64) - wofz(x + 1.2e-3j).real) / wofz(x + 1.2e-3j).real
+    assert 1e-7 < rel.max() < 3e-6
