@@ -75,6 +75,9 @@ def main():
                          "one-GPU box (all ranks share cuda:0, logL shards gathered through host memory)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="threads of the second CPU baseline (plain-C/OpenMP oracle); 0 = skip it")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = the config's batch per GPU (default, BASELINE's C -> D pattern); strong = the "
+                         "config's batch split over the GPUs")
     ap.add_argument("--pinned", action="store_true", help="with --host-api: P and logL in page-locked host memory")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent batches kept in flight (contexts + streams); 1 = the headline configuration")
@@ -110,6 +113,10 @@ def main():
     kw, batch, seed = workloads.config(args.config, hip_synth)
     if args.batch:
         batch = args.batch
+    if args.scaling == "strong" and world > 1:
+        if batch % world:
+            raise SystemExit(f"--scaling strong: batch {batch} is not a multiple of {world} ranks")
+        batch //= world                                  # per-rank rows; the job-wide batch stays the config's
     # every rank draws the job-wide matrix from one seed and keeps its contiguous row block
     P_all = workloads.draw_P(kw, batch * world, np.random.default_rng(seed), damped=2 if args.config == "E" else 0)
     P_host = np.ascontiguousarray(P_all[rank * batch:(rank + 1) * batch])
@@ -238,7 +245,7 @@ def main():
             "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "batches_in_flight": max(1, args.inflight if (world == 1 and not args.host_api) else 1), "entry": ("host pointers (PCIe inclusive%s)" % (", page-locked buffers" if args.pinned else "")) if args.host_api else "device pointers",
             "config": {"workload": f"BASELINE config {args.config}: CIV 1548/1550 synthetic spectrum" if args.config != "E"
                        else "BASELINE config E: HI 1215 damped", "batch_per_gpu": batch, "global_batch": batch * world,
