@@ -1299,7 +1299,7 @@ extern "C" int mcalf_model_batch_device(mcalf_ctx* ctx, const double* dP, int64_
     return launch(ctx, kModeModel, dP, batch, targonly ? 1 : 0, 0, nullptr, dflux, (hipStream_t)stream);
 }
 
-constexpr size_t kSmallDoubles = 2048;      // 16 KB of parameters (and as many results) go the zero-copy way
+constexpr size_t kSmallDoubles = 65536;     // up to 512 KB of parameters (and as many results) go the zero-copy way
 
 // Host-pointer entries: stage through the context's workspaces on its private stream.
 static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
