@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="B", choices=["A", "B", "C", "E"])
+    ap.add_argument("--config", default="B", choices=["A", "B", "C", "D", "E"])
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -113,6 +113,10 @@ def main():
     kw, batch, seed = workloads.config(args.config, hip_synth)
     if args.batch:
         batch = args.batch
+    if args.config == "D":                               # BASELINE config D: 32768 rows job-wide = 4096 per GPU on 8 GPUs
+        if batch % world:
+            raise SystemExit(f"config D: {batch} rows do not split over {world} ranks")
+        batch //= world
     if args.scaling == "strong" and world > 1:
         if batch % world:
             raise SystemExit(f"--scaling strong: batch {batch} is not a multiple of {world} ranks")
