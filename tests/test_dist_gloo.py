@@ -92,3 +92,29 @@ def test_single_process_plan_is_identity():
     plan = mdist.LogLGather(5, "cpu")
     plan.local.copy_(torch.arange(5, dtype=torch.float64))
     assert torch.equal(plan.gather(), torch.arange(5, dtype=torch.float64))
+
+
+def _one_rank_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        ring = mdist.LogLGather(6, "cpu", depth=2, always_collective=True)
+        assert ring.collective
+        for k in range(3):
+            ring.local.copy_(torch.arange(6, dtype=torch.float64) + k)
+            ring.gather_async()
+        q.put(ring.finish().numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_can_still_run_the_collective():
+    """bench.py's single-rank rehearsal of the gather path (MCALF_BENCH_FORCE_DIST) relies on this."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=120)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and np.array_equal(got, np.arange(6.0) + 2)
