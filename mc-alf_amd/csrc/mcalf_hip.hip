@@ -100,6 +100,7 @@ struct KArgs {
     int npix, ndim, ntiles, tile, n_cap, ncl_cap;
     int nlines, ncompmax, nfill, startind, endind, freespecres, freecont;
     int targonly, mode, jax_half, onecomp_fill, asymm;
+    int taps_shared;        // 1: fixed resolution -> every live point has the same LSF taps, stored once (row 0)
     int selfhalo;           // 1: single-tile spectrum whose halo entries are copies of the tile's own pixels (see fused kernel)
     double specres_fixed, contval_fixed, velstep, log2pi;
     double dnu_seg;         // largest |nu(first) - nu(last)| over the 64-pixel segments
@@ -374,7 +375,8 @@ __global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long ba
     const int rowlen = (a.mode == kModeOneComp) ? 5 : a.ndim;
     const double* p = a.P + (size_t)s * rowlen;
     double* recs = a.recs + (size_t)s * a.ncl_cap * kRecStride;
-    double* taps = a.taps + (size_t)s * (2 * a.n_cap + 8);
+    double* taps = a.taps + (a.taps_shared ? 0 : (size_t)s * (2 * a.n_cap + 8));
+    const bool writeTaps = !a.taps_shared || s == 0;
     // ---- 1. decode the parameter vector ---------------------------------------------------
     double R, cont;
     int nc, nfill_eff;
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long ba
         const double g = (lane > 2 * n) ? 0.0 : ((n == 0 && !kZeroPad) ? 1.0 : exp(-(dk * dk) * inv2s2) * amp);
         const double gsum = wave_allsum(g);
         wsum = g / gsum;
-        if (lane < ntap8) taps[lane] = wsum;
+        if (lane < ntap8 && writeTaps) taps[lane] = wsum;
     } else {
         double gsum = 0.0;
         for (int k = lane; k <= 2 * n; k += 64) {
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long ba
             const double dk = (double)(k - n);
             const double w = (k <= 2 * n) ? exp(-(dk * dk) * inv2s2) * amp / gsum : 0.0;   // zero-padded to 8
             wsum += w;
-            taps[k] = w;
+            if (writeTaps) taps[k] = w;
         }
     }
     const double bot = kZeroPad ? 1.0 : wave_allsum(wsum);
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     constexpr int kRecRegs = 2;                        // covers ncl_cap <= 128 without a second trip
     const int recTotal = a.ncl_cap * kRecStride, tapTotal = 2 * a.n_cap + 8;
     const double* gr = a.recs + (size_t)s * recTotal;
-    const double* gt = a.taps + (size_t)s * tapTotal;
+    const double* gt = a.taps + (a.taps_shared ? 0 : (size_t)s * tapTotal);
     double rreg[kRecRegs];
 #pragma unroll
     for (int i = 0; i < kRecRegs; ++i) rreg[i] = (tid + i * kBlock < recTotal) ? gr[tid + i * kBlock] : 0.0;
@@ -1222,6 +1224,7 @@ static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int
     a.freespecres = ctx->freespecres; a.freecont = ctx->freecont;
     a.targonly = targonly; a.mode = mode; a.jax_half = ctx->jax_half; a.onecomp_fill = onecomp_fill;
     a.selfhalo = ctx->selfhalo;
+    a.taps_shared = (!ctx->freespecres && mode != kModeOneComp) ? 1 : 0;
     a.specres_fixed = ctx->specres_fixed; a.contval_fixed = ctx->contval_fixed; a.velstep = ctx->velstep;
     a.log2pi = std::log(2.0 * M_PI);
     a.prior_lo = from_cube ? ctx->d_prior : nullptr;
