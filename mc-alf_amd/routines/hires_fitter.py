@@ -85,19 +85,15 @@ class als_fitter:
                  Nrange=[11.5, 16], brange=[1, 30], zrange=None, Nrangefill=[11.5, 16], brangefill=[1, 30],
                  wrangefill=None, coldef=['Wave', 'Flux', 'Err'], Gpriors=None, Asymmlike=False, debug=False,
                  *, spectrum=None, linepars=None, velstep=None, conv_mode="numpy", device=-1, gauss_cdf=None):
-        self.debug = debug
-        self.specfile = specfile
-        self.fitrange = fitrange
-        self.fitlines = fitlines
-        self.Gpriors = Gpriors
-        self.Asymmlike = Asymmlike
-        if self.Asymmlike:
-            print("Running asymmetric likelihood")
+        # public attributes under the names the reference's callers read (hires_fitter.py:46-60)
+        self.specfile, self.fitrange, self.fitlines = specfile, fitrange, fitlines
+        self.Gpriors, self.Asymmlike, self.debug = Gpriors, bool(Asymmlike), debug
         self.specres = list(np.atleast_1d(specres))
         self.contval = list(np.atleast_1d(contval))
-        self.ncompmin = ncomp[0]
-        self.ncompmax = ncomp[1]
+        self.ncompmin, self.ncompmax = ncomp
         self.nfill = nfill
+        if self.Asymmlike:
+            print("Running asymmetric likelihood")
         self.freecont = len(self.contval) > 1          # hires_fitter.py:54-57
         self.freespecres = len(self.specres) > 1       # :59-62
         self.clight = 2.9979245e5                      # :65
@@ -241,18 +237,20 @@ class als_fitter:
 
     # ------------------------------------------------------------------ prior transforms
     def _scale_cube_pc(self, cube):
-        """hires_fitter.py:202-209."""
-        cube2 = np.copy(cube)
-        for ii in range(len(cube)):
-            cube2[ii] = cube2[ii] * np.ptp(self.bounds[ii]) + np.min(self.bounds[ii])
-            if ii == self.startind:
-                cube2[ii] = int(cube2[ii])
-        return cube2
+        """Prior transform for PolyChord / dyPolyChord (hires_fitter.py:202-209): a new vector
+        `cube * ptp(bounds) + min(bounds)` (separately rounded multiply and add, as numpy evaluates it),
+        with the ncomp slot truncated like Python's int()."""
+        theta = np.array(cube, dtype=float, copy=True)
+        theta *= self._hi - self._lo
+        theta += self._lo
+        theta[self.startind] = int(theta[self.startind])
+        return theta
 
     def _scale_cube_mn(self, cube, ndim, nparam):
-        """hires_fitter.py:211-216 (in place)."""
-        for ii in range(ndim):
-            cube[ii] = cube[ii] * np.ptp(self.bounds[ii]) + np.min(self.bounds[ii])
+        """Prior transform for MultiNest (hires_fitter.py:211-216): rescales the first `ndim` entries of
+        `cube` -- possibly a C double pointer -- in place; the ncomp slot keeps its fraction."""
+        for k in range(ndim):
+            cube[k] = cube[k] * (self._hi[k] - self._lo[k]) + self._lo[k]
         return cube
 
     def scale_cube_batch(self, cubes, int_ncomp=True):
@@ -284,18 +282,20 @@ class als_fitter:
         return (theta, logL) if return_theta else logL
 
     def lnprior(self, p):
-        """hires_fitter.py:218-234."""
-        ndim = len(p)
-        if all(b[0] <= v <= b[1] for v, b in zip(p, self.bounds)):
-            pav = 0
-            if self.Gpriors is not None:
-                for par in range(ndim):
-                    if self.Gpriors[2 * par] != 'none' and self.Gpriors[(2 * par) + 1] != 'none':
-                        val = float(self.Gpriors[2 * par])
-                        sig = float(self.Gpriors[(2 * par) + 1])
-                        pav += -0.5 * (((p[par] - val) / sig) ** 2 + np.log(2. * np.pi * sig ** 2))
-            return pav
-        return -np.inf
+        """Log prior (hires_fitter.py:218-234): -inf outside the box; inside, the sum of the Gaussian priors
+        given as (mean, sigma) string pairs in `Gpriors` ('none' = flat), 0 without any."""
+        p = np.asarray(p, dtype=float)
+        if np.any(p < self._lo) or np.any(p > self._hi) or np.any(np.isnan(p)):
+            return -np.inf
+        total = 0
+        if self.Gpriors is not None:
+            for k, value in enumerate(p):
+                mean, sigma = self.Gpriors[2 * k], self.Gpriors[2 * k + 1]
+                if mean == 'none' or sigma == 'none':
+                    continue
+                mean, sigma = float(mean), float(sigma)
+                total += -0.5 * (((value - mean) / sigma) ** 2 + np.log(2. * np.pi * sigma ** 2))
+        return total
 
     # ------------------------------------------------------------------ batched entries
     def _rows(self, P, width):

@@ -485,19 +485,20 @@ def calc_w_intended(prob: Problem, p, lineid: int = 0) -> float:
 
 
 def pc_sort_components(postsamples: np.ndarray) -> np.ndarray:
-    """The per-sample redshift sort of hires_fitter.py:726-743, loop for loop."""
-    postsamples = np.array(postsamples, dtype=float, copy=True)
-    postsorted = np.copy(postsamples)
-    ncols = len(postsorted[0])
-    startind = (ncols - 1) % 3
-    for ii in range(len(postsamples[:, 0])):
-        thisncomp = int(postsamples[ii, startind])
-        thisendind = startind + 1 + 3 * thisncomp
-        postsamples[ii, thisendind:] = 99
-        postsorted[ii, thisendind:] = 99
-        zsort = np.argsort(postsamples[ii, startind + 2:startind + 1 + 3 * thisncomp:3])
-        for jj in range(len(zsort)):
-            postsorted[ii, 3 * jj + startind + 1:3 * jj + 3 + startind + 1] = \
-                postsamples[ii, 3 * zsort[jj] + np.array([0, 1, 2]) + startind + 1]
-        postsorted[postsorted == 99] = np.nan
-    return postsorted
+    """What hires_fitter.py:726-743 leaves in `postsorted`: per posterior sample the (N, z, b) triples of
+    its ACTIVE components ordered by increasing redshift, every slot beyond them NaN (and any entry that
+    happens to equal the reference's 99 placeholder NaN as well, :743).  The slots before the first triple
+    (resolution / continuum / ncomp) are untouched; their count is `(ncols - 1) % 3` (:728)."""
+    rows = np.asarray(postsamples, dtype=float)
+    first = (rows.shape[1] - 1) % 3 + 1
+    result = []
+    for row in rows.tolist():
+        active = int(row[first - 1])
+        triples = [row[first + 3 * c: first + 3 * c + 3] for c in range(active)]
+        triples.sort(key=lambda t: t[1])                    # stable, like argsort on distinct redshifts
+        flat = [v for t in triples for v in t]
+        tail = [float("nan")] * (len(row) - first - len(flat))
+        result.append(row[:first] + flat + tail)
+    out = np.array(result, dtype=float).reshape(rows.shape)
+    out[out == 99] = np.nan
+    return out
