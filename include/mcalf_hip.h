@@ -18,7 +18,7 @@
  *   mcalf_chi2_batch       <- als_fitter.chi2                         hires_fitter.py:236-248
  *   mcalf_scale_cube_batch <- _scale_cube_pc / _scale_cube_mn         hires_fitter.py:202-216
  *   mcalf_loglike_cube_batch <- lnlhood_pc(_scale_cube_pc(cube))      hires_fitter.py:202-209,250-262
- *   mcalf_voigt_hjerting   <- scipy.special.wofz(u + i a).real        hires_fitter.py:365
+ *   mcalf_voigt_hjerting[_nodes] <- scipy.special.wofz(u + i a).real  hires_fitter.py:365
  *                             / voigt_jax.hjert                       voigt_jax.py:121-127
  *
  * Ownership: the context owns all device memory it allocates.  Host pointers passed to
