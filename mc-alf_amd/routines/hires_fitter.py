@@ -45,10 +45,15 @@ def sigma_clipped_median(x, sigma=3.0, maxiters=5):
 
 
 def _read_ascii_table(path, coldef):
-    """Minimal stand-in for `astropy.io.ascii.read` (hires_fitter.py:69-72) on whitespace
-    tables whose column names are either a `# Wave Flux Err` comment line (np.savetxt
-    header, as in the reference's testdata) or a bare first line."""
-    names, skip = None, 0
+    """Minimal stand-in for `astropy.io.ascii.read` (hires_fitter.py:69-72) on plain-text tables: whitespace-,
+    comma- or tab-separated columns whose names are either a `# Wave Flux Err` comment line (np.savetxt header,
+    as in the reference's testdata) or a bare first line (what `ascii.write` / a CSV export produce); without any
+    header the columns are taken in `coldef` order."""
+    names, skip, delim = None, 0, None
+
+    def split(text):
+        return [t.strip() for t in text.split(",")] if "," in text else text.split()
+
     with open(path) as fh:
         for line in fh:
             s = line.strip()
@@ -56,16 +61,18 @@ def _read_ascii_table(path, coldef):
                 skip += 1
                 continue
             if s.startswith("#"):
-                names = s.lstrip("#").split()
+                names = split(s.lstrip("#").strip())
                 skip += 1
                 continue
+            if "," in s:
+                delim = ","
             try:
-                [float(t) for t in s.split()]
+                [float(t) for t in split(s)]
             except ValueError:
-                names = s.split()
+                names = split(s)
                 skip += 1
             break
-    data = np.loadtxt(path, comments="#", skiprows=skip, ndmin=2)
+    data = np.loadtxt(path, comments="#", skiprows=skip, ndmin=2, delimiter=delim)
     if names is None or len(names) != data.shape[1]:
         names = list(coldef)
     idx = [names.index(c) for c in coldef]

@@ -69,3 +69,27 @@ def test_workload_boxes_match_the_oracle_problem():
     P = workloads.draw_P(kw, 32, np.random.default_rng(seed))
     assert P.shape == (32, 7) and np.all(P[:, 0] == 2.0)
     assert np.all((P >= workloads.bounds_of(kw)[:, 0]) & (P <= workloads.bounds_of(kw)[:, 1]))
+
+
+@pytest.mark.parametrize("style", ["savetxt_header", "bare_header", "csv", "tabs", "no_header", "reordered_csv"])
+def test_table_reader_accepts_the_usual_plain_text_layouts(tmp_path, style):
+    """The stand-in for astropy's ascii.read (hires_fitter.py:69-72): same three columns whatever the layout."""
+    wl = np.linspace(6180.0, 6181.0, 7)
+    fl = 1.0 + 0.01 * np.arange(7)
+    er = np.full(7, 0.02)
+    rows = [(float(w), float(f), float(e)) for w, f, e in zip(wl, fl, er)]      # plain floats: repr round-trips
+    path = tmp_path / "spec.txt"
+    if style == "savetxt_header":
+        np.savetxt(path, np.c_[wl, fl, er], header="Wave Flux Err")
+    elif style == "bare_header":
+        path.write_text("Wave Flux Err\n" + "\n".join("%r %r %r" % t for t in rows) + "\n")
+    elif style == "csv":
+        path.write_text("Wave,Flux,Err\n" + "\n".join("%r,%r,%r" % t for t in rows) + "\n")
+    elif style == "tabs":
+        path.write_text("Wave\tFlux\tErr\n" + "\n".join("%r\t%r\t%r" % t for t in rows) + "\n")
+    elif style == "no_header":
+        np.savetxt(path, np.c_[wl, fl, er])
+    else:
+        path.write_text("Err, Wave, Flux\n" + "\n".join("%r, %r, %r" % (e, w, f) for w, f, e in rows) + "\n")
+    got = hires_fitter._read_ascii_table(str(path), ["Wave", "Flux", "Err"])
+    assert np.array_equal(got[0], wl) and np.array_equal(got[1], fl) and np.array_equal(got[2], er)
