@@ -255,8 +255,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "batches_in_flight": max(1, args.inflight if (world == 1 and not args.host_api) else 1), "entry": ("host pointers (PCIe inclusive%s)" % (", page-locked buffers" if args.pinned else "")) if args.host_api else "device pointers",
-            "config": {"workload": f"BASELINE config {args.config}: CIV 1548/1550 synthetic spectrum" if args.config != "E"
-                       else "BASELINE config E: HI 1215 damped", "batch_per_gpu": batch, "global_batch": batch * world,
+            "config": {"workload": ("BASELINE config A: CIV 1548/1550, the reference's multicomponent mock spectrum (tests/golden)"
+                                    if args.config == "A" else "BASELINE config E: HI 1215 damped" if args.config == "E"
+                                    else f"BASELINE config {args.config}: CIV 1548/1550 synthetic spectrum"), "batch_per_gpu": batch, "global_batch": batch * world,
                        "npix": npix, "ncomp": list(kw["ncomp"]), "nlines": nlines, "nfill": fit.nfill, "ndim": ndim,
                        "specres": list(kw["specres"]), "lsf_taps": 2 * n_half + 1, "tiles_per_sample": fit.info.ntiles,
                        "parallelism": (f"dp{world} rows sharded, {'gloo REHEARSAL on one GPU' if rehearsal else 'RCCL'} gather of logL to rank 0"
