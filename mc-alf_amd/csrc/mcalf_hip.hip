@@ -753,7 +753,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
                 double term = is2[m] * (d * d);
                 if (a.mode == kModeLogL) term = (term - lg[m]) + a.log2pi;                 // :294
                 if (live && !isnan(term)) acc += term;                                     // np.nansum
-                if (live && mval != 0.0) nnz += 1.0;
+                if (a.mode == kModeChi2 && live && mval != 0.0) nnz += 1.0;      // only chi2 asks whether the model is all zero (:241)
                 if (a.asymm) {                                                             // :298-302
                     const double resid = d / er[m];
                     if (live && resid > 4.0) c4 += 1.0;
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     if (a.mode == kModeModel || a.mode == kModeOneComp) return;
 
     acc = wave_sum_to_last(acc);
-    nnz = wave_sum_to_last(nnz);
+    if (a.mode == kModeChi2) nnz = wave_sum_to_last(nnz);
     const int wave = tid >> 6;
     if ((tid & 63) == 63) { sRed[wave] = acc; sRed[kWaves + wave] = nnz; }
     double t4 = 0.0, t5 = 0.0;
