@@ -1,13 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the MC-ALF likelihood hot path on MI355X.
 
-A "step" is one `loglike_batch` pass over one batch of synthetic live points (BASELINE.json
-config B at N=1: batch=1024, ncomp=8, CIV doublet, npix=4000, fixed 8 km/s LSF) with the
-parameter matrix already resident in HBM and logL left in HBM.  With N GPUs every rank
-runs the same per-GPU batch (weak scaling; config B -> 8 x B, the C -> D pattern of
-BASELINE.json) and the per-sample logL shards are gathered to rank 0 over RCCL each step.
+A "step" is one pass of the hot path over one batch of synthetic live points.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+  N = 1 (default)  BASELINE.json config C -- the largest single-GPU configuration: batch 4096, ncomp 8-11,
+                   4 fillers, LSF resolution floated in [8, 9] km/s, CIV doublet, 4000 pixels.
+  N > 1 (default)  BASELINE.json config D -- the same problem with 32768 live points job-wide, cut into
+                   contiguous row blocks over the N ranks (strong scaling: the job-wide batch is fixed), the
+                   per-sample logL gathered to rank 0 over RCCL every step.  The N = 1 line carries the
+                   one-GPU time of the same 32768 rows (`strong_scaling_reference`).
+
+`value` is timed through the device-pointer entry, parameters resident in HBM when the timed region starts and
+logL left in HBM (the bench contract).  `value_host_api` is the same K steps through the host-pointer entry
+`mcalf_loglike_batch` -- H2D of P and D2H of logL inside every step, SURVEY.md section 8(d)'s definition --
+measured in the same run and printed next to it.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -16,6 +24,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -37,6 +46,15 @@ from mcalf_amd import dist as mdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 peak
+MIN_PASS_MS = 50.0             # a timed pass shorter than this is repeated and the median pass reported
+
+WORKLOAD_LABEL = {
+    "A": "BASELINE config A: CIV 1548/1550, the reference's multicomponent mock spectrum (tests/golden)",
+    "B": "BASELINE config B: CIV 1548/1550 synthetic spectrum, ncomp 8, fixed 8 km/s LSF",
+    "C": "BASELINE config C: CIV 1548/1550 synthetic spectrum, ncomp 8-11 + 4 fillers, LSF floated in [8, 9] km/s",
+    "D": "BASELINE config D: config C's problem with 32768 live points job-wide",
+    "E": "BASELINE config E: HI 1215 damped, ncomp 16, 20000 pixels",
+}
 
 
 def hip_synth(kw, p):
@@ -45,18 +63,24 @@ def hip_synth(kw, p):
         return fit.reconstruct_spec(np.asarray(p, dtype=float))
 
 
+def oracle_problem(kw):
+    from oracle import numpy_oracle as oracle
+    wl, flux, err = kw["spectrum"]
+    return oracle.Problem(wl, flux, err, kw["linepars"], tuple(kw["ncomp"]), nfill=kw.get("nfill", 0),
+                          specres=kw["specres"], Nrange=kw["Nrange"], brange=kw["brange"], zrange=kw["zrange"],
+                          Nrangefill=kw.get("Nrangefill", [11.5, 16]), brangefill=kw.get("brangefill", [1, 30]),
+                          fitrange=kw["fitrange"])
+
+
 def cpu_baseline(kw, P, budget_s):
     """Time the numpy/scipy oracle (the closest runnable stand-in for the reference's numpy
     path) on a bounded sample of the same workload.  Checker/baseline only."""
     from oracle import numpy_oracle as oracle
-    wl, flux, err = kw["spectrum"]
-    prob = oracle.Problem(wl, flux, err, kw["linepars"], tuple(kw["ncomp"]), nfill=kw.get("nfill", 0),
-                          specres=kw["specres"], Nrange=kw["Nrange"], brange=kw["brange"], zrange=kw["zrange"],
-                          Nrangefill=kw.get("Nrangefill", [11.5, 16]), brangefill=kw.get("brangefill", [1, 30]),
-                          fitrange=kw["fitrange"])
+    prob = oracle_problem(kw)
     oracle.lnlhood_worker(prob, P[0])          # warm
     vals, t0, done = [], time.perf_counter(), 0
-    while time.perf_counter() - t0 < budget_s or done < (len(P) if budget_s <= 0 else 0):   # cycle over the batch until the time budget is spent (budget 0: every row once)
+    # cycle over the batch until the time budget is spent (budget 0: every row once)
+    while time.perf_counter() - t0 < budget_s or done < (len(P) if budget_s <= 0 else 0):
         row = P[done % len(P)]
         v = oracle.lnlhood_worker(prob, row)
         if done < len(P):
@@ -66,30 +90,38 @@ def cpu_baseline(kw, P, budget_s):
     return np.array(vals), dt, done
 
 
+def load_profile_json(name, config):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            return json.load(fh).get(config)
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="B", choices=["A", "B", "C", "D", "E"])
-    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 = skip)")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default=None, choices=["A", "B", "C", "D", "E"],
+                    help="default: C on one GPU (largest single-GPU BASELINE configuration), D on several")
+    ap.add_argument("--batch", type=int, default=0, help="override the job-wide batch of the configuration")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N>1: strong = the configuration's batch split over the ranks (default; BASELINE's "
+                         "north-star asks for strong scaling), weak = the configuration's batch on every rank")
+    ap.add_argument("--chunks", type=int, default=-1,
+                    help="row blocks per batch inside the library (mcalf_set_chunks): -1 library default, 0 automatic, "
+                         "1 = one fused launch per step (what the rocprofv3 summaries in profiles/ are taken with)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline time budget (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the plain-C/OpenMP CPU baseline; 0 = every host core (os.cpu_count()), -1 = skip")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real multi-GPU path) or gloo: a rehearsal of the N>1 control flow on a "
                          "one-GPU box (all ranks share cuda:0, logL shards gathered through host memory)")
-    ap.add_argument("--cpu-threads", type=int, default=16,
-                    help="threads of the second CPU baseline (plain-C/OpenMP oracle); 0 = skip it")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N>1: weak = the config's batch per GPU (default, BASELINE's C -> D pattern); strong = the "
-                         "config's batch split over the GPUs")
-    ap.add_argument("--pinned", action="store_true", help="with --host-api: P and logL in page-locked host memory")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer (PCIe-inclusive) passes")
+    ap.add_argument("--no-strong-ref", action="store_true", help="N=1: skip the config-D-on-one-GPU reference")
     ap.add_argument("--inflight", type=int, default=1,
-                    help="independent batches kept in flight (contexts + streams); 1 = the headline configuration")
-    ap.add_argument("--no-launch-events", action="store_true",
-                    help="diagnostic: do not bracket each fused launch with HIP events (measures their overhead)")
-    ap.add_argument("--host-api", action="store_true",
-                    help="diagnostic: time the host-pointer entry (H2D of P and D2H of logL inside the step); "
-                         "never the headline value")
+                    help="diagnostic: independent batches kept in flight (contexts + streams); 1 = the headline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,6 +129,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    config = args.config or ("C" if world == 1 else "D")
+    scaling = args.scaling or "strong"
     # MCALF_BENCH_FORCE_DIST=1 (with torch.distributed.run --nproc-per-node 1) runs the N>1 code path --
     # process group, RCCL gather ring, barrier, all_reduce -- on a single rank: a one-GPU check of the
     # collective plumbing the driver's multi-GPU runs use.
@@ -113,22 +147,25 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    rccl_ranks = dist.get_world_size() if use_dist else 1
 
-    kw, batch, seed = workloads.config(args.config, hip_synth)
+    kw, job_batch, seed = workloads.config(config, hip_synth)
     if args.batch:
-        batch = args.batch
-    if args.config == "D":                               # BASELINE config D: 32768 rows job-wide = 4096 per GPU on 8 GPUs
-        if batch % world:
-            raise SystemExit(f"config D: {batch} rows do not split over {world} ranks")
-        batch //= world
-    if args.scaling == "strong" and world > 1:
-        if batch % world:
-            raise SystemExit(f"--scaling strong: batch {batch} is not a multiple of {world} ranks")
-        batch //= world                                  # per-rank rows; the job-wide batch stays the config's
+        job_batch = args.batch
+    if scaling == "strong":
+        if job_batch % world:
+            raise SystemExit(f"--scaling strong: batch {job_batch} is not a multiple of {world} ranks")
+        batch = job_batch // world                       # per-rank rows; the job-wide batch stays the config's
+    else:
+        batch = job_batch
+    damped = 2 if config == "E" else 0
     # every rank draws the job-wide matrix from one seed and keeps its contiguous row block
-    P_all = workloads.draw_P(kw, batch * world, np.random.default_rng(seed), damped=2 if args.config == "E" else 0)
+    P_all = workloads.draw_P(kw, batch * world, np.random.default_rng(seed), damped=damped)
     P_host = np.ascontiguousarray(P_all[rank * batch:(rank + 1) * batch])
+    del P_all
     fit = mcalf_amd.als_fitter(None, device=local_rank, **kw)
+    if args.chunks >= 0:
+        fit.set_chunks(args.chunks)
     npix, ndim, nlines = fit.obj_wl.size, fit.ndim, fit.numlines
     nc = P_host[:, fit.startind].astype(int)
     comp_pix = float(nc.sum()) * npix                       # component x pixel evals per step (this rank)
@@ -144,25 +181,18 @@ def main():
     st = C.c_void_p(stream.cuda_stream)
     # optional: further independent batches in flight, each with its own context, stream and output
     extra = []
-    if args.inflight > 1 and world == 1 and not args.host_api:
+    if args.inflight > 1 and world == 1:
         for _ in range(args.inflight - 1):
             f2 = mcalf_amd.als_fitter(None, device=local_rank, **kw)
             _lib.check(f2._lib.mcalf_reserve(f2._ctx, batch), f2._ctx)
             s2 = torch.cuda.Stream()
             extra.append((f2, s2, torch.empty(batch, dtype=torch.float64, device=dev)))
     turn = [0]
-    P_host_api, out_host_api = P_host, None
-    if args.host_api and args.pinned:                    # page-locked host buffers: the copies become plain DMA
-        P_host_api = torch.from_numpy(P_host).pin_memory().numpy()
-        out_host_api = torch.empty(batch, dtype=torch.float64).pin_memory().numpy()
     launch = fit._lib.mcalf_loglike_batch_device
     ctx, pP = fit._ctx, dP.data_ptr()
     last_out = [dlogL]
 
     def step():
-        if args.host_api:
-            fit.loglike_batch(P_host_api, out=out_host_api)
-            return
         if extra:
             k = turn[0] % (len(extra) + 1)
             turn[0] += 1
@@ -190,40 +220,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_pass(fn, k):
+        """Exactly k steps bracketed by barrier + synchronize on both sides; seconds."""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        fence()
+        return time.perf_counter() - t0
+
+    def measure(fn, k, red_dev):
+        """Median over repeated timed passes (each pass = exactly k steps); every pass time is the MAX over ranks."""
+        first = timed_pass(fn, k)
+        npass = 1 if first * 1e3 >= MIN_PASS_MS else min(15, 2 * int(math.ceil(MIN_PASS_MS / max(first * 1e3, 1e-3))) + 1)
+        times = [first] + [timed_pass(fn, k) for _ in range(npass - 1)]
+        t = torch.tensor(times, dtype=torch.float64, device=red_dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times = sorted(float(v) for v in t.tolist())
+        return times[len(times) // 2], times
+
+    red_dev = "cpu" if rehearsal else dev
     for _ in range(args.warmup):
         step()
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    fence()
-    elapsed = time.perf_counter() - t0
-    red_dev = "cpu" if rehearsal else dev
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    elapsed, pass_times = measure(step, args.steps, red_dev)
     tot = torch.tensor([comp_pix, line_pix], dtype=torch.float64, device=red_dev)
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
     comp_pix_job, line_pix_job = (float(v) for v in tot.tolist())
-
-    # dominant kernel: average launch duration from HIP events on the launch stream (N=1: the
-    # stream carries nothing but the fused kernel; N>1: the gather is on RCCL's own stream)
-    stream_ms = ev0.elapsed_time(ev1) / args.steps        # everything on the launch stream per step
-    # Dominant kernel alone: a second pass of K launches, each bracketed by HIP events on the launch
-    # stream inside the library.  Kept out of the timed region because the brackets themselves cost
-    # ~5 us per step (measured), which would otherwise be charged to `value`.
-    kern_ms, nl = C.c_double(0.0), C.c_int32(0)
-    if not args.host_api and not args.no_launch_events:
-        _lib.check(fit._lib.mcalf_profile_begin(fit._ctx, args.steps), fit._ctx)
-        for _ in range(args.steps):
-            step()
-        fence()
-        _lib.check(fit._lib.mcalf_profile_end(fit._ctx, C.byref(kern_ms), C.byref(nl)), fit._ctx)
-    kern_ms = kern_ms.value if nl.value else stream_ms      # mean duration of mcalf_fused_kernel alone
     logL_dev = last_out[0].cpu().numpy()
     gather_check = None
     if use_dist and rank == 0 and gathered[0] is not None:
@@ -233,47 +257,115 @@ def main():
         gather_check = {"rows": int(g.size), "own_block_equal": bool(np.array_equal(g[:batch], logL_dev)),
                         "all_finite": bool(np.isfinite(g).all())}
 
+    # Dominant kernel alone: a further pass of K launches, each bracketed by HIP events on the launch stream
+    # inside the library (one fused launch per step: the library issues the batch as ONE row block while it is
+    # being profiled).  Kept out of the timed region because the brackets themselves cost ~5 us per step.
+    kern_ms, nl = C.c_double(0.0), C.c_int32(0)
+    _lib.check(fit._lib.mcalf_profile_begin(fit._ctx, args.steps), fit._ctx)
+    for _ in range(args.steps):
+        step()
+    fence()
+    _lib.check(fit._lib.mcalf_profile_end(fit._ctx, C.byref(kern_ms), C.byref(nl)), fit._ctx)
+    kern_ms = kern_ms.value if nl.value else elapsed / args.steps * 1e3
+
+    # PCIe-inclusive passes through the host-pointer entry (N = 1): pageable numpy arrays as a sampler holds
+    # them, then page-locked ones
+    host_api = None
+    if world == 1 and not args.no_host_api:
+        out_host = np.empty(batch)
+        fit.loglike_batch(P_host, out=out_host)
+        t_host, _ = measure(lambda: fit.loglike_batch(P_host, out=out_host), args.steps, red_dev)
+        same = bool(np.array_equal(out_host, logL_dev))
+        P_pin = torch.from_numpy(P_host).pin_memory().numpy()
+        out_pin = torch.empty(batch, dtype=torch.float64).pin_memory().numpy()
+        fit.loglike_batch(P_pin, out=out_pin)
+        t_pin, _ = measure(lambda: fit.loglike_batch(P_pin, out=out_pin), args.steps, red_dev)
+        host_api = {"ms_per_step": t_host / args.steps * 1e3, "value": comp_pix * args.steps / t_host,
+                    "ms_per_step_pinned": t_pin / args.steps * 1e3, "value_pinned": comp_pix * args.steps / t_pin,
+                    "bit_equal_to_device_entry": same,
+                    "what": "mcalf_loglike_batch: H2D of P [batch][ndim] f64 and D2H of logL [batch] f64 inside every "
+                            "step, one synchronous call per step (SURVEY.md 8(d)); pageable numpy arrays / page-locked arrays"}
+
+    # N = 1 leg of the strong-scaling job: config D's 32768 rows on this one GPU
+    strong_ref = None
+    if world == 1 and config == "C" and not args.no_strong_ref and not args.batch:
+        kwD, batchD, seedD = workloads.config("D", hip_synth)
+        PD = workloads.draw_P(kwD, batchD, np.random.default_rng(seedD))
+        dPD = torch.from_numpy(PD).to(dev)
+        outD = torch.empty(batchD, dtype=torch.float64, device=dev)
+        _lib.check(fit._lib.mcalf_reserve(fit._ctx, batchD), fit._ctx)
+
+        def stepD():
+            rc = launch(ctx, dPD.data_ptr(), batchD, outD.data_ptr(), st)
+            if rc:
+                _lib.check(rc, ctx)
+        for _ in range(2):
+            stepD()
+        kD = max(3, args.steps // 8)
+        tD, _ = measure(stepD, kD, red_dev)
+        ncD = PD[:, fit.startind].astype(int)
+        strong_ref = {"workload": WORKLOAD_LABEL["D"] + ", all rows on ONE GPU", "global_batch": batchD, "steps": kD,
+                      "ms_per_step": tD / kD * 1e3, "value": float(ncD.sum()) * npix * kD / tD}
+        del dPD, outD
+
     out = None
     if rank == 0:
         n_half = fit.info.n_cap
         alg_bytes = (8 * ndim + 8) * batch + 24 * npix
         alg_flops = 40.0 * line_pix + (31 + 4 * n_half) * npix * batch
         ach_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None                       # HBM bytes per launch from rocprofv3 PMC passes (offline, profiles/)
-        try:
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-                tr = json.load(fh).get(args.config)
-            if tr and not args.batch:
-                traffic = tr["traffic_bytes_per_launch"]
-        except (OSError, ValueError):
-            pass
+        std_batch = not args.batch and (world == 1 or scaling == "strong")
+        tr = load_profile_json("traffic.json", config) if std_batch and world == 1 else None
+        pmc = load_profile_json("pmc.json", config) if std_batch and world == 1 else None
+        ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": "component-pixel Voigt evals/s (sum_s ncomp_s * npix / t), logL batch on MI355X",
             "value": comp_pix_job * args.steps / elapsed,
             "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic", "batches_in_flight": max(1, args.inflight if (world == 1 and not args.host_api) else 1), "entry": ("host pointers (PCIe inclusive%s)" % (", page-locked buffers" if args.pinned else "")) if args.host_api else "device pointers",
-            "config": {"workload": ("BASELINE config A: CIV 1548/1550, the reference's multicomponent mock spectrum (tests/golden)"
-                                    if args.config == "A" else "BASELINE config E: HI 1215 damped" if args.config == "E"
-                                    else f"BASELINE config {args.config}: CIV 1548/1550 synthetic spectrum"), "batch_per_gpu": batch, "global_batch": batch * world,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "entry": "device pointers (P resident in HBM, logL left in HBM)",
+            "timing": {"passes": len(pass_times), "steps_per_pass": args.steps, "reported": "median pass",
+                       "pass_ms": [round(t * 1e3, 4) for t in pass_times]},
+            "batches_in_flight": max(1, args.inflight if world == 1 else 1),
+            "config": {"workload": WORKLOAD_LABEL[config], "batch_per_gpu": batch, "global_batch": batch * world,
                        "npix": npix, "ncomp": list(kw["ncomp"]), "nlines": nlines, "nfill": fit.nfill, "ndim": ndim,
                        "specres": list(kw["specres"]), "lsf_taps": 2 * n_half + 1, "tiles_per_sample": fit.info.ntiles,
-                       "parallelism": (f"dp{world} rows sharded, {'gloo REHEARSAL on one GPU' if rehearsal else 'RCCL'} gather of logL to rank 0"
+                       "row_blocks_per_batch": fit.chunks_for(batch),
+                       "parallelism": (f"dp{world}: rows sharded in contiguous blocks, "
+                                       f"{'gloo REHEARSAL on one GPU' if rehearsal else 'RCCL'} gather of logL to rank 0 every step"
                                        if world > 1 else "single GPU")},
             "logL_per_s": batch * world * args.steps / elapsed,
             "line_pixel_evals_per_s": line_pix_job * args.steps / elapsed,
-            "kernel_ms": kern_ms, "stream_ms_per_step": stream_ms,
+            "kernel_ms": kern_ms,
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mcalf_fused_kernel", "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "fused path is FP64-VALU bound, not HBM bound (SURVEY.md 8d); see roofline_valu"},
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": tr["traffic_bytes_per_launch"] if tr else None,
+                         "kernel": "mcalf_fused_kernel (one launch over the whole batch)",
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "the fused path is FP64-VALU bound, not HBM bound (arithmetic intensity > 1e3 FLOP/B, "
+                                 "SURVEY.md 8d): the HBM fraction is ~1e-3 by construction; see roofline_valu"},
             "roofline_valu": {"bound": "fp64_valu", "achieved": alg_flops / (kern_ms * 1e-3) / 1e12,
                               "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": alg_flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                              "algorithmic_flops_per_launch": alg_flops},
+                              "algorithmic_flops_per_launch": alg_flops,
+                              "note": "frac prices SURVEY 8(d)'s nominal 40 FLOP per line-pixel; far-wing interpolation "
+                                      "skips most of those evaluations, so frac is a throughput-equivalent, not pipe "
+                                      "utilisation -- valu_busy (PMC) is the utilisation"},
         }
+        if pmc:
+            out["roofline_valu"].update({k: pmc[k] for k in ("valu_busy", "executed_flops_per_launch", "source") if k in pmc})
+            if "executed_flops_per_launch" in pmc:
+                out["roofline_valu"]["executed_tflops"] = pmc["executed_flops_per_launch"] / (kern_ms * 1e-3) / 1e12
+        if host_api:
+            out["value_host_api"] = host_api["value"]
+            out["ms_per_step_host_api"] = host_api["ms_per_step"]
+            out["host_api"] = host_api
+        if strong_ref:
+            out["strong_scaling_reference"] = strong_ref
+        if use_dist:
+            out["rccl_ranks"] = rccl_ranks
         if args.cpu_seconds > 0 and world == 1:          # the CPU baseline is an N=1 figure (rank 0 only)
             vals, dt, done = cpu_baseline(kw, P_host, args.cpu_seconds)
             k = len(vals)
@@ -284,17 +376,12 @@ def main():
                           f"numpy/scipy float64 oracle (oracle/numpy_oracle.py), {dt:.1f} s, {dt / done * 1e3:.2f} ms per logL",
                 "host_cpus": os.cpu_count()}
             out["parity"] = {"max_abs_dlogL_vs_oracle": float(np.abs(vals - logL_dev[:k]).max()), "rows": k}
-            if args.cpu_threads > 0:
-                # second CPU figure: the plain-C/OpenMP restatement (oracle/c), several host threads
-                from oracle import c_oracle, numpy_oracle
-                wl_, flux_, err_ = kw["spectrum"]
-                prob = numpy_oracle.Problem(wl_, flux_, err_, kw["linepars"], tuple(kw["ncomp"]), nfill=kw.get("nfill", 0),
-                                            specres=kw["specres"], Nrange=kw["Nrange"], brange=kw["brange"],
-                                            zrange=kw["zrange"], Nrangefill=kw.get("Nrangefill", [11.5, 16]),
-                                            brangefill=kw.get("brangefill", [1, 30]), fitrange=kw["fitrange"])
-                nthr = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-                co = c_oracle.COracle(prob, threads=nthr)
-                rows = P_host[: min(batch, 64 * nthr)]
+            if args.cpu_threads >= 0:
+                # second CPU figure: the plain-C/OpenMP restatement (oracle/c) on every host core
+                from oracle import c_oracle
+                nthr = args.cpu_threads or (os.cpu_count() or 1)
+                co = c_oracle.COracle(oracle_problem(kw), threads=nthr)
+                rows = P_host[: min(batch, 16 * nthr)]
                 co.loglike_batch(rows[:nthr])
                 tc, reps = time.perf_counter(), 0
                 while time.perf_counter() - tc < 5.0:
@@ -302,8 +389,9 @@ def main():
                     reps += 1
                 dtc = time.perf_counter() - tc
                 out["cpu_baseline_c_openmp"] = {
-                    "value": reps * float(nc[: len(rows)].sum()) * npix / dtc, "unit": "evals/s", "cores": nthr, "kind": "port",
-                    "sample": f"{reps} x {len(rows)} rows, oracle/c/mcalf_oracle.c (gcc -O2 -fopenmp), {dtc:.1f} s",
+                    "value": reps * float(nc[: len(rows)].sum()) * npix / dtc, "unit": "evals/s", "cores": nthr,
+                    "kind": "port", "host_cpus": os.cpu_count(),
+                    "sample": f"{reps} x {len(rows)} rows, oracle/c/mcalf_oracle.c (gcc -O2 -fopenmp, {nthr} threads), {dtc:.1f} s",
                     "max_abs_dlogL_vs_gpu": float(np.abs(cvals - logL_dev[: len(rows)]).max())}
     if out is not None and world > 1 and args.cpu_seconds > 0:
         # N>1: no CPU timing, only a parity spot check of rank 0's first rows against the oracle
@@ -312,6 +400,8 @@ def main():
     if out is not None and gather_check is not None:
         out["gather_check"] = gather_check
     fit.close()
+    for f2, _, _ in extra:
+        f2.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -26,8 +26,10 @@
  * DEVICE pointers valid on the context's GPU and enqueue on the given hipStream_t
  * (passed as void*; NULL = the legacy default stream) without synchronising.
  *
- * Threading: a context is not re-entrant (one in-flight call per context); distinct
- * contexts are independent.
+ * Threading: a context is not re-entrant (one in-flight call per context, and every
+ * asynchronous call of a context on the same stream); distinct contexts are independent.
+ * A resolution beyond the provisioned specres_max makes a row's model NaN, its logL -inf and
+ * its chi2 +inf (the reference would allocate a longer kernel).
  */
 #ifndef MCALF_HIP_H
 #define MCALF_HIP_H
@@ -130,7 +132,21 @@ int mcalf_chi2_batch(mcalf_ctx* ctx, const double* P, int64_t batch, double* chi
  * alone (the per-line model calc_w integrates, hires_fitter.py:483). */
 int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batch, int32_t which, double* flux);
 
-/* Same, device pointers + stream, asynchronous. */
+/* Row blocks a batch is issued in (0 = automatic [default], 1 = one block, n <= 8).  With more than one block
+ * the blocks after the first run on context-owned streams between a fork event recorded on the caller's stream
+ * and join events that stream waits for: the call keeps plain stream semantics (and can be captured into a
+ * hipGraph), while the per-sample set-up kernel and the first workgroups of block k+1 fill the tail of block k.
+ * Results do not depend on the setting (every live point is evaluated independently).  The environment
+ * variable MCALF_CHUNKS gives the initial value. */
+int mcalf_set_chunks(mcalf_ctx* ctx, int32_t nchunks);
+/* Row blocks a *_device call of `batch` rows is issued in under the current setting. */
+int32_t mcalf_get_chunks(const mcalf_ctx* ctx, int64_t batch);
+
+/* Same, device pointers + stream, asynchronous.
+ * Stream rule: all asynchronous calls of ONE context must be issued on ONE stream (the context's per-sample
+ * workspaces are shared by its launches and ordered only by that stream); call mcalf_reserve(batch) first when
+ * the call is to be captured into a hipGraph or must not allocate (a *_device call otherwise grows the
+ * workspaces on first use, which synchronises the device). */
 int mcalf_loglike_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, double* dlogL, void* stream);
 int mcalf_model_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, int32_t targonly,
                              double* dflux, void* stream);

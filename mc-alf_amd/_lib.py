@@ -75,6 +75,8 @@ SYMBOLS = {
     "mcalf_last_error": (C.c_char_p, [_CTX]),
     "mcalf_version": (C.c_char_p, []),
     "mcalf_reserve": (C.c_int, [_CTX, C.c_int64]),
+    "mcalf_set_chunks": (C.c_int, [_CTX, C.c_int32]),
+    "mcalf_get_chunks": (C.c_int32, [_CTX, C.c_int64]),
     "mcalf_loglike_batch": (C.c_int, [_CTX, _PD, C.c_int64, _PD]),
     "mcalf_model_batch": (C.c_int, [_CTX, _PD, C.c_int64, C.c_int32, _PD]),
     "mcalf_chi2_batch": (C.c_int, [_CTX, _PD, C.c_int64, _PD]),

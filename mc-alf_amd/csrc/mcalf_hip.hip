@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -780,6 +781,9 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         double ssum = 0.0, scnt = 0.0;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) { ssum += sRed[w]; scnt += sRed[kWaves + w]; }
+        // LSF wider than the provisioned halo: the model was not computed (the reference would build a longer
+        // kernel); the row must not look like a valid likelihood -> logL = -inf, chi2 = +inf
+        if (bad) { ssum = INFINITY; scnt = 1.0; }
         MCALF_STAMP(6);
         MCALF_STAMP(7);
         if (a.ntiles == 1) {
@@ -834,6 +838,7 @@ __global__ void mcalf_scale_cube_kernel(const double* lo, const double* hi, cons
 using namespace mcalf;
 
 static thread_local std::string g_last_error;
+constexpr int kMaxChunks = 8;
 
 struct mcalf_ctx {
     int device = 0;
@@ -872,6 +877,16 @@ struct mcalf_ctx {
     // prior box of mcalf_set_prior (device copy in d_prior: lo[ndim] then hi[ndim])
     bool prior_set = false;
     int prior_int = 0;
+    // Chunked issue: a batch is cut into row blocks that go to the caller's stream and to context-owned
+    // auxiliary streams (fork / join through events), so that the set-up kernel and the first workgroups of
+    // block k+1 run in the tail of block k.  chunks_req: 0 = automatic, n = exactly n blocks (1 = off).
+    int chunks_req = 0;
+    int num_cu = 256;
+    hipStream_t aux[kMaxChunks - 1] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxChunks - 1] = {};
+    // page-locked staging of the host-pointer entries: parameter rows in, scalars out
+    double* h_stage = nullptr;
+    size_t cap_stage = 0;
 };
 
 static int set_err(mcalf_ctx* ctx, int code, const char* fmt, ...) {
@@ -944,7 +959,13 @@ extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (hipEvent_t e : ctx->ev_join)
+        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : ctx->aux)
+        if (st) (void)hipStreamDestroy(st);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1140,6 +1161,16 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     for (const void* k : kernels)
         HIP_TRY(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        const char* env = std::getenv("MCALF_CHUNKS");            // 0 / unset: automatic; n: exactly n row blocks
+        if (env && *env) {
+            const int v = std::atoi(env);
+            if (v >= 0 && v <= kMaxChunks) ctx->chunks_req = v;
+        }
+    }
     return MCALF_OK;
 }
 
@@ -1193,29 +1224,27 @@ extern "C" int mcalf_reserve(mcalf_ctx* ctx, int64_t batch) {
     return MCALF_OK;
 }
 
-// Enqueue the fused kernel (+ finalize when tiled) on `stream`.
+// Enqueue rows [row0, row0 + nrows) of a batch on `stream`: set-up kernel, fused kernel, finalize when tiled.
+// `chunk` selects the row of the shared tap table this block writes and reads (fixed-resolution contexts).
 // `from_cube`: dP holds unit-cube rows, mapped through the prior box while decoding; d_theta (optional)
 // receives the transformed rows.
-static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill,
-                  double* d_out, double* d_model, hipStream_t stream, bool from_cube = false,
-                  double* d_theta = nullptr) {
-    if (batch == 0) return MCALF_OK;
-    if (batch < 0 || batch * (int64_t)ctx->ntiles > 0x7fffffffLL)
-        return set_err(ctx, MCALF_ERR_RANGE, "batch %lld too large", (long long)batch);
+static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0, int64_t nrows, int chunk,
+                        int targonly, int onecomp_fill, double* d_out, double* d_model, hipStream_t stream,
+                        bool from_cube, double* d_theta, bool timed_ok) {
     const bool reduces = (mode == kModeLogL || mode == kModeChi2);
-    if (reduces && ctx->ntiles > 1) {
-        int rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4);
-        if (rc) return rc;
-    }
-    {
-        int rc = grow_sample_ws(ctx, batch);
-        if (rc) return rc;
-    }
+    const int rowlen = (mode == kModeOneComp) ? 5 : ctx->ndim;
+    const size_t tapTotal = 2 * (size_t)ctx->n_cap + 8;
     KArgs a;
-    a.recs = ctx->d_recs; a.taps = ctx->d_taps; a.hdr = ctx->d_hdr;
+    a.taps_shared = (!ctx->freespecres && mode != kModeOneComp) ? 1 : 0;
+    a.recs = ctx->d_recs + (size_t)row0 * ctx->ncl_cap * kRecStride;
+    a.taps = ctx->d_taps + (a.taps_shared ? (size_t)chunk : (size_t)row0) * tapTotal;
+    a.hdr = ctx->d_hdr + row0;
     a.nu = ctx->d_nu; a.obj = ctx->d_obj; a.ispec2 = ctx->d_ispec2; a.lgis = ctx->d_lgis; a.err = ctx->d_err;
     a.asymm = (mode == kModeLogL) ? ctx->asymm : 0; a.veto4 = ctx->veto4; a.veto5 = ctx->veto5;
-    a.P = dP; a.partial = ctx->d_partial; a.out = d_out; a.model = d_model;
+    a.P = dP + (size_t)row0 * rowlen;
+    a.partial = ctx->d_partial ? ctx->d_partial + (size_t)row0 * ctx->ntiles * 4 : nullptr;
+    a.out = d_out ? d_out + row0 : nullptr;
+    a.model = d_model ? d_model + (size_t)row0 * ctx->npix : nullptr;
     a.lines = ctx->d_lines; a.tabs = ctx->d_tabs; a.wtab = ctx->d_wtab; a.segok = ctx->d_segok; a.dnu_seg = ctx->dnu_seg;
     a.npix = (int)ctx->npix; a.ndim = ctx->ndim; a.ntiles = ctx->ntiles; a.tile = ctx->tile;
     a.n_cap = ctx->n_cap; a.ncl_cap = ctx->ncl_cap;
@@ -1224,20 +1253,19 @@ static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int
     a.freespecres = ctx->freespecres; a.freecont = ctx->freecont;
     a.targonly = targonly; a.mode = mode; a.jax_half = ctx->jax_half; a.onecomp_fill = onecomp_fill;
     a.selfhalo = ctx->selfhalo;
-    a.taps_shared = (!ctx->freespecres && mode != kModeOneComp) ? 1 : 0;
     a.specres_fixed = ctx->specres_fixed; a.contval_fixed = ctx->contval_fixed; a.velstep = ctx->velstep;
     a.log2pi = std::log(2.0 * M_PI);
     a.prior_lo = from_cube ? ctx->d_prior : nullptr;
     a.prior_hi = from_cube ? ctx->d_prior + ctx->ndim : nullptr;
-    a.theta_out = from_cube ? d_theta : nullptr;
+    a.theta_out = (from_cube && d_theta) ? d_theta + (size_t)row0 * ctx->ndim : nullptr;
     a.prior_int = ctx->prior_int;
-    const dim3 grid((unsigned)(batch * ctx->ntiles)), block(kBlock);
+    const dim3 grid((unsigned)(nrows * ctx->ntiles)), block(kBlock);
     if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX)
-        hipLaunchKernelGGL(mcalf_sample_kernel<true>, dim3((unsigned)batch), dim3(64), 0, stream, a, (long)batch);
+        hipLaunchKernelGGL(mcalf_sample_kernel<true>, dim3((unsigned)nrows), dim3(64), 0, stream, a, (long)nrows);
     else
-        hipLaunchKernelGGL(mcalf_sample_kernel<false>, dim3((unsigned)batch), dim3(64), 0, stream, a, (long)batch);
+        hipLaunchKernelGGL(mcalf_sample_kernel<false>, dim3((unsigned)nrows), dim3(64), 0, stream, a, (long)nrows);
     HIP_TRY(ctx, hipGetLastError());
-    const bool timed = ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
+    const bool timed = timed_ok && ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used], stream));
     const bool jaxmode = ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX;
     if (jaxmode && ctx->selfhalo) hipLaunchKernelGGL((mcalf_fused_kernel<true, true>), grid, block, ctx->lds_bytes, stream, a);
@@ -1251,10 +1279,79 @@ static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int
     }
     if (reduces && ctx->ntiles > 1) {
         const int fb = 256;
-        hipLaunchKernelGGL(mcalf_finalize_kernel, dim3((unsigned)((batch + fb - 1) / fb)), dim3(fb), 0, stream,
-                           ctx->d_partial, d_out, (long)batch, ctx->ntiles, mode, a.asymm, a.veto4, a.veto5);
+        hipLaunchKernelGGL(mcalf_finalize_kernel, dim3((unsigned)((nrows + fb - 1) / fb)), dim3(fb), 0, stream,
+                           a.partial, a.out, (long)nrows, ctx->ntiles, mode, a.asymm, a.veto4, a.veto5);
         HIP_TRY(ctx, hipGetLastError());
     }
+    return MCALF_OK;
+}
+
+// Row blocks a batch is issued in: the caller's request, or automatically two blocks once the batch fills the
+// chip several times over (each workgroup slot then sees >= 2 workgroups per block, so the split costs no
+// occupancy and the second block's set-up kernel + first wave of workgroups run in the tail of the first).
+static int pick_chunks(const mcalf_ctx* ctx, int64_t batch) {
+    int n = ctx->chunks_req;
+    if (n <= 0) {
+        const int64_t wgs = batch * ctx->ntiles, slots = 2LL * ctx->num_cu;
+        n = (wgs >= 4 * slots) ? 2 : 1;
+    }
+    if (n > kMaxChunks) n = kMaxChunks;
+    if ((int64_t)n > batch) n = (int)batch;
+    return n < 1 ? 1 : n;
+}
+
+static int ensure_aux(mcalf_ctx* ctx, int naux) {
+    if (!ctx->ev_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < naux; ++i) {
+        if (!ctx->aux[i]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+        if (!ctx->ev_join[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
+    }
+    return MCALF_OK;
+}
+
+static int64_t chunk_begin(int64_t batch, int nchunks, int c) { return batch * c / nchunks; }
+
+// Enqueue one batch on `stream` (asynchronous).  With several row blocks, blocks 1.. go to the context's
+// auxiliary streams between a fork event recorded on `stream` and join events `stream` waits for, so the call
+// keeps plain stream semantics for the caller (and can be captured into a hipGraph).
+static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill,
+                  double* d_out, double* d_model, hipStream_t stream, bool from_cube = false,
+                  double* d_theta = nullptr) {
+    if (batch == 0) return MCALF_OK;
+    if (batch < 0 || batch * (int64_t)ctx->ntiles > 0x7fffffffLL)
+        return set_err(ctx, MCALF_ERR_RANGE, "batch %lld too large", (long long)batch);
+    const bool reduces = (mode == kModeLogL || mode == kModeChi2);
+    int rc;
+    if (reduces && ctx->ntiles > 1 && (rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4)))
+        return rc;
+    if ((rc = grow_sample_ws(ctx, batch))) return rc;
+    const int nchunks = ctx->profiling ? 1 : pick_chunks(ctx, batch);
+    if (nchunks == 1)
+        return launch_range(ctx, mode, dP, 0, batch, 0, targonly, onecomp_fill, d_out, d_model, stream, from_cube,
+                            d_theta, true);
+    if ((rc = ensure_aux(ctx, nchunks - 1))) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, stream));
+    for (int c = 0; c < nchunks; ++c) {
+        const int64_t r0 = chunk_begin(batch, nchunks, c), r1 = chunk_begin(batch, nchunks, c + 1);
+        hipStream_t st = (c == 0) ? stream : ctx->aux[c - 1];
+        if (c > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0));
+        if ((rc = launch_range(ctx, mode, dP, r0, r1 - r0, c, targonly, onecomp_fill, d_out, d_model, st, from_cube,
+                               d_theta, false)))
+            return rc;
+        if (c > 0) HIP_TRY(ctx, hipEventRecord(ctx->ev_join[c - 1], st));
+    }
+    for (int c = 1; c < nchunks; ++c) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_join[c - 1], 0));
+    return MCALF_OK;
+}
+
+extern "C" int32_t mcalf_get_chunks(const mcalf_ctx* ctx, int64_t batch) {
+    return (ctx && batch > 0) ? pick_chunks(ctx, batch) : 0;
+}
+
+extern "C" int mcalf_set_chunks(mcalf_ctx* ctx, int32_t nchunks) {
+    if (!ctx || nchunks < 0 || nchunks > kMaxChunks)
+        return set_err(ctx, MCALF_ERR_INVALID, "nchunks must be 0 (automatic) .. %d", kMaxChunks);
+    ctx->chunks_req = nchunks;
     return MCALF_OK;
 }
 
@@ -1304,6 +1401,65 @@ extern "C" int mcalf_model_batch_device(mcalf_ctx* ctx, const double* dP, int64_
 
 constexpr size_t kSmallDoubles = 65536;     // up to 512 KB of parameters (and as many results) go the zero-copy way
 
+// True when `p` is page-locked host memory the copy engines can read / write directly.
+static bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();                          // ordinary pageable memory: not an error for us
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+// Large scalar-output batches through host pointers: the rows are cut into blocks that alternate between two
+// streams, each block being  H2D of its parameter rows -> set-up + fused kernels -> D2H of its results,  so the
+// PCIe traffic and the per-block set-up of block k+1 run under the kernels of block k.  Pageable caller memory
+// is staged through a page-locked block of the context (the host copies block k+1 in while the GPU works on
+// block k); page-locked caller memory is used by the copy engines directly.
+static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly,
+                              int fill, double* out_scalar) {
+    int rc;
+    int nchunks = ctx->chunks_req > 0 ? ctx->chunks_req : 4;
+    if (nchunks > kMaxChunks) nchunks = kMaxChunks;
+    if ((int64_t)nchunks > batch) nchunks = (int)batch;
+    if (ctx->profiling) nchunks = 1;
+    if ((rc = ensure_aux(ctx, 1))) return rc;
+    const bool reduces = (mode == kModeLogL || mode == kModeChi2);
+    if (reduces && ctx->ntiles > 1 && (rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4)))
+        return rc;
+    if ((rc = grow_sample_ws(ctx, batch))) return rc;
+    const bool pin_in = is_pinned_host(P), pin_out = is_pinned_host(out_scalar);
+    const size_t need = (pin_in ? 0 : (size_t)batch * rowlen) + (pin_out ? 0 : (size_t)batch);
+    if (need > ctx->cap_stage) {
+        if (ctx->h_stage) HIP_TRY(ctx, hipHostFree(ctx->h_stage));
+        ctx->h_stage = nullptr; ctx->cap_stage = 0;
+        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_stage, need * sizeof(double), hipHostMallocDefault));
+        ctx->cap_stage = need;
+    }
+    double* stage_in = pin_in ? nullptr : ctx->h_stage;
+    double* stage_out = pin_out ? out_scalar : ctx->h_stage + (pin_in ? 0 : (size_t)batch * rowlen);
+    hipStream_t streams[2] = {ctx->stream, ctx->aux[0]};
+    for (int c = 0; c < nchunks; ++c) {
+        const int64_t r0 = chunk_begin(batch, nchunks, c), n = chunk_begin(batch, nchunks, c + 1) - r0;
+        hipStream_t st = streams[c & 1];
+        const double* src = P + (size_t)r0 * rowlen;
+        if (!pin_in) {
+            std::memcpy(stage_in + (size_t)r0 * rowlen, src, (size_t)n * rowlen * sizeof(double));
+            src = stage_in + (size_t)r0 * rowlen;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_P + (size_t)r0 * rowlen, src, (size_t)n * rowlen * sizeof(double),
+                                    hipMemcpyHostToDevice, st));
+        if ((rc = launch_range(ctx, mode, ctx->d_P, r0, n, c, targonly, fill, ctx->d_out, nullptr, st, false, nullptr,
+                               nchunks == 1)))
+            return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(stage_out + r0, ctx->d_out + r0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (nchunks > 1) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux[0]));
+    if (!pin_out) std::memcpy(out_scalar, stage_out, (size_t)batch * sizeof(double));
+    return MCALF_OK;
+}
+
 // Host-pointer entries: stage through the context's workspaces on its private stream.
 static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
                     double* out_scalar, double* out_model) {
@@ -1329,6 +1485,7 @@ static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
     if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, (size_t)batch * rowlen))) return rc;
     if (out_scalar && (rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
     if (out_model && (rc = grow(ctx, &ctx->d_model, &ctx->cap_model, (size_t)batch * ctx->npix))) return rc;
+    if (out_scalar && !out_model) return run_host_pipelined(ctx, mode, P, batch, rowlen, targonly, fill, out_scalar);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_P, P, (size_t)batch * rowlen * sizeof(double), hipMemcpyHostToDevice,
                                 ctx->stream));
     rc = launch(ctx, mode, ctx->d_P, batch, targonly, fill, out_scalar ? ctx->d_out : nullptr,

@@ -229,6 +229,14 @@ class als_fitter:
             self._lib.mcalf_destroy(self._ctx)
             self._ctx = None
 
+    def set_chunks(self, nchunks):
+        """Row blocks a batch is issued in inside the library (0 = automatic, 1 = one launch per batch); results
+        do not depend on it."""
+        _lib.check(self._lib.mcalf_set_chunks(self._ctx, int(nchunks)), self._ctx)
+
+    def chunks_for(self, batch):
+        return int(self._lib.mcalf_get_chunks(self._ctx, int(batch)))
+
     def __del__(self):
         try:
             self.close()
@@ -349,6 +357,15 @@ class als_fitter:
         """Rows (R, cont, N, z, b) -> single-component spectra.  `fill`: the filler line;
         `line=k`: line k of the multiplet alone; default: every line of the component."""
         Q = self._rows(Q, 5)
+        # The LDS halo of the context is provisioned from max(specres); the reference would simply build a longer
+        # kernel (hires_fitter.py:458-459), so a wider request is an error here rather than a NaN spectrum.
+        R = Q[:, 0]
+        with np.errstate(invalid="ignore"):
+            half = np.where(R > self.velstep, np.ceil(3.0348 * (R / 2.354820) / self.velstep), 0.0)
+        if self.conv_mode != "jax" and np.any(half > self.info.n_cap):
+            raise ValueError(f"specresolution {float(np.nanmax(R)):g} km/s needs an LSF kernel wider than the context was "
+                             f"provisioned for (max(specres) = {max(self.specres):g} km/s); construct als_fitter with a "
+                             "larger specres")
         out = np.empty((Q.shape[0], self.obj_wl.size))
         which = 1 if fill else (0 if line is None else 2 + int(line))
         pd = C.POINTER(C.c_double)
