@@ -132,12 +132,14 @@ int mcalf_chi2_batch(mcalf_ctx* ctx, const double* P, int64_t batch, double* chi
  * alone (the per-line model calc_w integrates, hires_fitter.py:483). */
 int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batch, int32_t which, double* flux);
 
-/* Row blocks a batch is issued in (0 = automatic [default], 1 = one block, n <= 8).  With more than one block
- * the blocks after the first run on context-owned streams between a fork event recorded on the caller's stream
- * and join events that stream waits for: the call keeps plain stream semantics (and can be captured into a
- * hipGraph), while the per-sample set-up kernel and the first workgroups of block k+1 fill the tail of block k.
- * Results do not depend on the setting (every live point is evaluated independently).  The environment
- * variable MCALF_CHUNKS gives the initial value. */
+/* Row blocks a batch is issued in (0 = automatic [default], n <= 8 = exactly n).  Automatic means ONE block
+ * for the *_device entries (the persistent fused kernel leaves no launch tail worth filling; measured) and FOUR
+ * for the host-pointer entries with large batches, where block k+1's H2D copy and per-sample set-up run under
+ * block k's kernel and block k's D2H copy under block k+1's.  With more than one block in a *_device call the
+ * blocks after the first run on context-owned streams between a fork event recorded on the caller's stream and
+ * join events that stream waits for: the call keeps plain stream semantics (and can be captured into a
+ * hipGraph).  Results do not depend on the setting (every live point is evaluated independently).  The
+ * environment variable MCALF_CHUNKS gives the initial value. */
 int mcalf_set_chunks(mcalf_ctx* ctx, int32_t nchunks);
 /* Row blocks a *_device call of `batch` rows is issued in under the current setting. */
 int32_t mcalf_get_chunks(const mcalf_ctx* ctx, int64_t batch);

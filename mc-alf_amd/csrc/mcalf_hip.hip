@@ -44,6 +44,7 @@ constexpr int kZFLds = VT_ZF_OFF + 2;
 constexpr int kLinesPerSync = MCALF_LINES_PER_SYNC;
 static_assert(kBlock == 64 * VT_INODES, "one interpolation weight per thread");
 static_assert(VT_NTOT <= 512 && (kZ0Lds % 2) == 0 && (kZFLds % 2) == 0 && (kTabPad % 2) == 0, "LDS table layout");
+constexpr int kRedDoubles = 3 * kWaves + 2;   // per-wave partials (sum, count, scratch) + the next work-item index
 constexpr int kTileSlack = 16;           // zero-filled entries past the halo (sliding-window over-read)
 constexpr size_t kLdsBudget = 78 * 1024;   // two workgroups per CU (160 KiB); needs the MaxDynamicSharedMemorySize attribute
 #ifndef MCALF_FAR_INTERP
@@ -112,6 +113,9 @@ struct KArgs {
     const double* prior_hi;
     double* theta_out;      // [batch][ndim] transformed parameters, or nullptr
     int prior_int;          // 1: int() on the ncomp slot (_scale_cube_pc), 0: leave (_scale_cube_mn)
+    // persistent fused kernel: work items (live point x tile) of this launch and its item queue
+    int nitems, persist;
+    unsigned int* queue;    // reset to 0 by the set-up kernel of the same launch
 };
 
 // LDS flux tile, "mod-8 planar": element i lives in plane (i & 7) at index (i >> 3).  The convolution
@@ -373,6 +377,7 @@ __global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long ba
     const long s = blockIdx.x;
     if (s >= batch) return;
     const int lane = threadIdx.x;
+    if (s == 0 && lane == 0) *a.queue = 0u;          // item queue of the fused kernel that follows on the stream
     const int rowlen = (a.mode == kModeOneComp) ? 5 : a.ndim;
     const double* p = a.P + (size_t)s * rowlen;
     double* recs = a.recs + (size_t)s * a.ncl_cap * kRecStride;
@@ -507,291 +512,361 @@ __device__ __forceinline__ void eval_general_lines(const double* __restrict__ sR
 #ifndef MCALF_MIN_WAVES
 #define MCALF_MIN_WAVES 4
 #endif
+// Everything the next work item needs from global memory, requested while the current item is still in its
+// convolution / likelihood phase (the loads then have the whole reduction to land in).
+struct ItemLoads {
+    double treg[(VT_NY * VT_NTOT + kBlock - 1) / kBlock];   // this thread's slice of the universal table T
+    double rreg[2];                                         // its slice of the sample's records (covers ncl_cap <= 128)
+    double tapreg;                                          // its LSF tap
+    double nu[kPpt];                                        // pixel frequencies of the tile
+    double nuNode;                                          // this lane's interpolation node
+    unsigned long long tileMask;                            // interpolable segments of the tile
+    SampleHdr hd;
+};
+
+// Issue every global load of work item w (one memory round trip; the record and tap copies run to their
+// provisioned sizes, which do not depend on the header: slots beyond the sample's own counts hold stale
+// values that are never read).
+template <bool kZeroPad, bool selfHalo>
+__device__ __forceinline__ void request_item(const KArgs& a, int w, int tid, ItemLoads& L) {
+    // The thread index is laundered through an empty asm so that the (item-invariant) load addresses are formed
+    // here, from one register, instead of being hoisted out of the item loop and kept alive -- ~30 registers --
+    // through the component loop, which sits at the kernel's 128-register limit.
+    asm volatile("" : "+v"(tid));
+    constexpr int kTRegs = (VT_NY * VT_NTOT + kBlock - 1) / kBlock;
+    constexpr int kRecRegs = 2;
+    const int recTotal = a.ncl_cap * kRecStride, tapTotal = 2 * a.n_cap + 8;
+    const int s = w / a.ntiles;
+    const int tileIdx = w - s * a.ntiles;
+#pragma unroll
+    for (int i = 0; i < kTRegs; ++i) {
+        const int idx = tid + i * kBlock;
+        L.treg[i] = (idx < VT_NY * VT_NTOT) ? a.tabs[idx] : 0.0;
+    }
+    L.hd = a.hdr[s];
+    const double* gr = a.recs + (size_t)s * recTotal;
+    const double* gt = a.taps + (a.taps_shared ? 0 : (size_t)s * tapTotal);
+#pragma unroll
+    for (int i = 0; i < kRecRegs; ++i) L.rreg[i] = (tid + i * kBlock < recTotal) ? gr[tid + i * kBlock] : 0.0;
+    L.tapreg = (tid < tapTotal) ? gt[tid] : 0.0;
+    const int t0 = tileIdx * a.tile;
+    const int ext0 = selfHalo ? 0 : t0 - a.n_cap;
+#pragma unroll
+    for (int j = 0; j < kPpt; ++j) {
+        int e = ext0 + tid + j * kBlock;
+        if (!selfHalo && (e < 0 || e >= a.npix)) {          // (self-halo: nu is padded to the thread count)
+            if (kZeroPad) e = 0;                             // jnp.convolve 'same' zero padding (:674)
+            else { e %= a.npix; if (e < 0) e += a.npix; }    // astropy boundary='wrap'
+        }
+        L.nu[j] = a.nu[e];
+    }
+    L.nuNode = 0.0;
+    L.tileMask = 0;
+    if (kFarInterp) {
+        const int wv = tid >> 6, ln = tid & 63;
+        int e = ext0 + 64 * wv + kBlock * (ln >> 3) + VT_INTERP_NODES[ln & 7];
+        if (!selfHalo && (e < 0 || e >= a.npix)) { e %= a.npix; if (e < 0) e += a.npix; }   // such segments are never interpolated
+        L.nuNode = a.nu[e];
+        L.tileMask = a.segok[tileIdx];                                         // bit m = segment m = wave + 8 j
+    }
+}
+
+// PERSISTENT kernel: the grid is the number of workgroup slots of the chip (2 per CU), and every workgroup walks
+// over work items w = (live point, pixel tile): its first item is blockIdx.x, the following ones come from an
+// atomic queue (a.queue, reset by the set-up kernel of the same launch), so that fast and slow samples balance
+// out.  Per item nothing is re-launched: the next item's records / taps / table slices / frequencies are
+// requested before the likelihood terms of the current one and written to LDS behind the barrier that ends it.
+// Every wave leaves the item loop at the same item count (the queue value is broadcast through LDS), so no wave
+// is ever left behind a barrier.
 template <bool kZeroPad, bool kSelfHalo>
 __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {
     extern __shared__ __align__(16) double smem[];
     double* sTab = smem;                                   // 2 x kLinesPerSync folded tables
     double* sRec = sTab + 2 * kLinesPerSync * kTabPad;                     // ncl_cap * 8
     double* sW = sRec + a.ncl_cap * kRecStride;            // taps, zero-padded to a multiple of 8
-    double* sRed = sW + (2 * a.n_cap + 8);                 // 3 * kWaves
-    double* sWt = sRed + 3 * kWaves;                       // [8][64] interpolation weights, node-major
+    double* sRed = sW + (2 * a.n_cap + 8);                 // kRedDoubles: 3 * kWaves partials + the next item index
+    double* sWt = sRed + kRedDoubles;                      // [8][64] interpolation weights, node-major
     double* sF = sWt + 64 * VT_INODES;                        // tile_doubles(tile + 2 n_cap)
+    int* sNext = reinterpret_cast<int*>(sRed + 3 * kWaves);
 
-    MCALF_STAMP(0);
-    MCALF_SUB(0);
-    const int tid = threadIdx.x;
-    const int s = blockIdx.x / a.ntiles;
-    const int tileIdx = blockIdx.x - s * a.ntiles;
+    const int tid0 = threadIdx.x;
     // The universal table T lives in the LDS region that later holds the flux tile (T is dead once
     // the component loop ends).  Each thread folds ONE coefficient slot per line.
     double* sT = sF;
     constexpr int kTRegs = (VT_NY * VT_NTOT + kBlock - 1) / kBlock;
-    double treg[kTRegs];                               // loads issued now, written to LDS after the set-up math
-#pragma unroll
-    for (int i = 0; i < kTRegs; ++i) {
-        const int idx = tid + i * kBlock;
-        treg[i] = (idx < VT_NY * VT_NTOT) ? a.tabs[idx] : 0.0;
-    }
-    if (kFarInterp) sWt[(tid & 7) * 64 + (tid >> 3)] = a.wtab[tid];      // kBlock == 64 * VT_INODES
-    const bool hasCoef = tid < VT_NTOT;
-    const int coefPos = tid + (tid >= VT_Z0_OFF ? 1 : 0) + (tid >= VT_ZF_OFF ? 1 : 0);
-    const bool coreCoef = tid < VT_NCORE;
-
-    // The tile always carries the full provisioned halo n_cap (so that its 64-pixel segments are the
-    // same for every sample); a sample with a shorter kernel simply starts `shift` entries in.
-    //
-    // Self-halo mode (a spectrum that fits ONE tile, the usual case): the periodic halo of the convolution
-    // consists of copies of the tile's own pixels, so only the npix real pixels are evaluated -- thread index =
-    // pixel index, every 64-pixel segment starts at a multiple of 64 and none crosses the seam -- and each
-    // flux value is stored at its body position and, near the ends, at its halo position too.  (With the halo
-    // evaluated as part of the tile, the segments that contain the seam cannot be interpolated; the three
-    // waves that own them then hold every barrier of the component loop back.)
-    constexpr bool selfHalo = kSelfHalo;               // (a.selfhalo chooses the instantiation on the host)
-    const int t0 = tileIdx * a.tile;
-    const int tlen = min(a.tile, a.npix - t0);
-    const int ext0 = selfHalo ? 0 : t0 - a.n_cap;
-    const int extCount = tlen + 2 * a.n_cap;
-    double nu[kPpt], tau[kPpt];
-#pragma unroll
-    for (int j = 0; j < kPpt; ++j) {
-        const int idx = tid + j * kBlock;
-        int e = ext0 + idx;
-        bool zero = false;
-        if (!selfHalo && (e < 0 || e >= a.npix)) {          // (self-halo: nu is padded to the thread count)
-            if (kZeroPad) { zero = true; e = 0; }            // jnp.convolve 'same' zero padding (:674)
-            else { e %= a.npix; if (e < 0) e += a.npix; }    // astropy boundary='wrap'
-        }
-        nu[j] = a.nu[e];
-        tau[j] = (zero && idx < extCount) ? INFINITY : 0.0;  // exp(-inf) = 0
-    }
-    // far-wing interpolation state: this lane's node pixel, the wave's interpolable segments
-    double nuNode = 0.0, farNode = 0.0;
-    unsigned long long segOk = 0, tileMask = 0;
-    if (kFarInterp) {
-        const int wv = tid >> 6, ln = tid & 63;
-        int e = ext0 + 64 * wv + kBlock * (ln >> 3) + VT_INTERP_NODES[ln & 7];
-        if (!selfHalo && (e < 0 || e >= a.npix)) { e %= a.npix; if (e < 0) e += a.npix; }   // such segments are never interpolated
-        nuNode = a.nu[e];
-        tileMask = a.segok[tileIdx];                                           // bit m = segment m = wave + 8 j
-    }
-
-    MCALF_SUB(1);
-    // ---- 1. per-sample set-up comes from mcalf_sample_kernel: header, records, taps -----------------
-    // Every global load of the set-up is issued before the first one is consumed (one memory round trip
-    // instead of three): the record and tap copies run to their provisioned sizes, which do not depend on
-    // the header (slots beyond the sample's own counts hold stale values that are never read).
-    const SampleHdr hd = a.hdr[s];
     constexpr int kRecRegs = 2;                        // covers ncl_cap <= 128 without a second trip
+    constexpr bool selfHalo = kSelfHalo;               // (a.selfhalo chooses the instantiation on the host)
+    if (kFarInterp) sWt[(tid0 & 7) * 64 + (tid0 >> 3)] = a.wtab[tid0];      // kBlock == 64 * VT_INODES
     const int recTotal = a.ncl_cap * kRecStride, tapTotal = 2 * a.n_cap + 8;
-    const double* gr = a.recs + (size_t)s * recTotal;
-    const double* gt = a.taps + (a.taps_shared ? 0 : (size_t)s * tapTotal);
-    double rreg[kRecRegs];
-#pragma unroll
-    for (int i = 0; i < kRecRegs; ++i) rreg[i] = (tid + i * kBlock < recTotal) ? gr[tid + i * kBlock] : 0.0;
-    const double treg0 = (tid < tapTotal) ? gt[tid] : 0.0;
+    const int nItems = a.nitems;
 
-    if (kFarInterp) {
-        const int wv = tid >> 6;
-#pragma unroll
-        for (int j = 0; j < kPpt; ++j) segOk |= ((tileMask >> (wv + 8 * j)) & 1ULL) << (8 * j);
-        segOk = uniform64(segOk);
-    }
-    const double cont = hd.cont, bot = hd.bot;
-    const int ncl = hd.ncl, n = hd.n;
-    const bool bad = hd.bad != 0;
-    const int ntap8 = (2 * n + 1 + 7) & ~7;
-#pragma unroll
-    for (int i = 0; i < kRecRegs; ++i)
-        if (tid + i * kBlock < recTotal) sRec[tid + i * kBlock] = rreg[i];
-    for (int i = tid + kRecRegs * kBlock; i < recTotal; i += kBlock) sRec[i] = gr[i];
-    if (tid < tapTotal) sW[tid] = treg0;
-    for (int i = tid + kBlock; i < tapTotal; i += kBlock) sW[i] = gt[i];
-    MCALF_SUB(2);
-#pragma unroll
-    for (int i = 0; i < kTRegs; ++i) {
-        const int idx = tid + i * kBlock;
-        if (idx < VT_NY * VT_NTOT) sT[idx] = treg[i];
-    }
+    int w = blockIdx.x;                                // grid <= nItems
+    ItemLoads L;
+    request_item<kZeroPad, kSelfHalo>(a, w, tid0, L);
 
-    MCALF_SUB(3);
-    MCALF_STAMP(1);
-    // ---- 2. tau for this thread's pixels ----------------------------------------------------
-    const int shift = a.n_cap - n;
-    __syncthreads();                                   // publishes sRec, sW, sT
-    MCALF_SUB(5);
-    MCALF_STAMP(2);
-    int buf = 0;
-#ifdef MCALF_ABL_NOLOOP   // ablation builds only (tools/); never defined in the product build
-    const int ncl_run = 0;
-#else
-    const int ncl_run = ncl;
-#endif
-    // kLinesPerSync lines are folded per workgroup barrier (their tables are double-buffered), which
-    // halves the barriers and averages the per-wave core/wing imbalance over more work.
-    for (int cl0 = 0; cl0 < ncl_run; cl0 += kLinesPerSync) {
-#if MCALF_BALANCE_PRIO
-        // Wave priority falls as the workgroup progresses, so of the two workgroups sharing a CU the one
-        // that is behind gets the issue slots (they finish together instead of the older one first).
-        if (4 * cl0 < ncl_run) __builtin_amdgcn_s_setprio(3);
-        else if (4 * cl0 < 2 * ncl_run) __builtin_amdgcn_s_setprio(2);
-        else if (4 * cl0 < 3 * ncl_run) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-#endif
-        double* tabs = sTab + buf * (kLinesPerSync * kTabPad);
-        if (hasCoef) {
-            double Tn[VT_NY];
+    while (true) {
+        MCALF_STAMP(0);
+        // Per item the thread index passes through an empty asm: everything derived from it (LDS offsets, tile
+        // positions, global addresses -- dozens of registers) is then formed where it is used instead of being
+        // hoisted out of the item loop and kept alive through the component loop, which sits at the kernel's
+        // 128-register limit.
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const bool hasCoef = tid < VT_NTOT;
+        const int coefPos = tid + (tid >= VT_Z0_OFF ? 1 : 0) + (tid >= VT_ZF_OFF ? 1 : 0);
+        const bool coreCoef = tid < VT_NCORE;
+        const int s = w / a.ntiles;
+        const int tileIdx = w - s * a.ntiles;
+        // ---- 1. per-sample set-up comes from mcalf_sample_kernel: header, records, taps -----------------
+        // The tile always carries the full provisioned halo n_cap (so that its 64-pixel segments are the
+        // same for every sample); a sample with a shorter kernel simply starts `shift` entries in.
+        //
+        // Self-halo mode (a spectrum that fits ONE tile, the usual case): the periodic halo of the convolution
+        // consists of copies of the tile's own pixels, so only the npix real pixels are evaluated -- thread index =
+        // pixel index, every 64-pixel segment starts at a multiple of 64 and none crosses the seam -- and each
+        // flux value is stored at its body position and, near the ends, at its halo position too.  (With the halo
+        // evaluated as part of the tile, the segments that contain the seam cannot be interpolated; the three
+        // waves that own them then hold every barrier of the component loop back.)
+        const int t0 = tileIdx * a.tile;
+        const int tlen = min(a.tile, a.npix - t0);
+        const int ext0 = selfHalo ? 0 : t0 - a.n_cap;
+        const int extCount = tlen + 2 * a.n_cap;
+        double nu[kPpt], tau[kPpt];
 #pragma unroll
-            for (int nn = 0; nn < VT_NY; ++nn) Tn[nn] = sT[nn * VT_NTOT + tid];
-#pragma unroll
-            for (int l = 0; l < kLinesPerSync; ++l) {
-                // no test per line: past the last record the last one is folded again into a slot nobody
-                // reads, which keeps the group's folds independent chains the scheduler can interleave
-                const double* rec = sRec + min(cl0 + l, ncl_run - 1) * kRecStride;
-                tabs[l * kTabPad + coefPos] = fold_coef(Tn, rec[3], coreCoef ? rec[4] : rec[5]);
-            }
+        for (int j = 0; j < kPpt; ++j) {
+            const int idx = tid + j * kBlock;
+            const int e = ext0 + idx;
+            const bool zero = kZeroPad && !selfHalo && (e < 0 || e >= a.npix);
+            nu[j] = L.nu[j];
+            tau[j] = (zero && idx < extCount) ? INFINITY : 0.0;  // exp(-inf) = 0
         }
-        __syncthreads();
-        buf ^= 1;
-#pragma unroll 1                 // one copy of the (large) per-line body: keeps the loop inside the instruction cache
-        for (int l = 0; l < kLinesPerSync; ++l) {
-            if (cl0 + l < ncl_run)
-                eval_line(tabs + l * kTabPad, sRec + (cl0 + l) * kRecStride, nu, tau, nuNode, farNode, segOk);
-        }
-    }
-    if (hd.ngeneral > 0 && ncl_run > 0) eval_general_lines(sRec, ncl, nu, tau);
-    MCALF_STAMP(3);
-#if MCALF_BALANCE_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-    // Interpolate the far-wing node sums to the pixels (tau[j] += sum_k W[lane][k] F[segment j][node k]),
-    // then flux = exp(-tau) into the LDS tile.  The node sums travel through the (now dead) folded-table
-    // region, one 64-entry row per wave; the tile holds only the sample's own halo n (<= n_cap).
-    double wrow[VT_INODES];
-    double* sFar = sTab + (tid >> 6) * 64;
-    if (kFarInterp) {
-        __syncthreads();                               // every wave is done reading the folded tables
-        sFar[tid & 63] = farNode;
-#pragma unroll
-        for (int k = 0; k < VT_INODES; ++k) wrow[k] = sWt[k * 64 + (tid & 63)];
-    }
-    const int extTight = tlen + 2 * n;
-#pragma unroll
-    for (int j = 0; j < kPpt; ++j) {
-        double tj = tau[j];
+        // far-wing interpolation state: this lane's node pixel, the wave's interpolable segments
+        const double nuNode = L.nuNode;
+        double farNode = 0.0;
+        unsigned long long segOk = 0;
         if (kFarInterp) {
-            double add = 0.0;
+            const int wv = tid >> 6;
 #pragma unroll
-            for (int k = 0; k < VT_INODES; ++k) add = fma(wrow[k], sFar[8 * j + k], add);
-            tj += add;
+            for (int j = 0; j < kPpt; ++j) segOk |= ((L.tileMask >> (wv + 8 * j)) & 1ULL) << (8 * j);
+            segOk = uniform64(segOk);
         }
-        const double fl = exp_neg(tj);                 // :377 (product of exp == exp of sum)
-        if (selfHalo) {
-            const int p = tid + j * kBlock;            // pixel index; tile layout [n halo | npix body | n halo]
-            if (p < a.npix) {
-                sF[tile_pos(p + n)] = fl;
-                // periodic copies (astropy boundary='wrap'); the JAX path pads with zeros instead (:674)
-                if (p < n) sF[tile_pos(p + n + a.npix)] = kZeroPad ? 0.0 : fl;
-                if (p >= a.npix - n) sF[tile_pos(p + n - a.npix)] = kZeroPad ? 0.0 : fl;
-            }
-        } else {
-            const int pos = tid + j * kBlock - shift;
-            if (pos >= 0 && pos < extTight) sF[tile_pos(pos)] = fl;
+        const SampleHdr hd = L.hd;
+        const double cont = hd.cont, bot = hd.bot;
+        const int ncl = hd.ncl, n = hd.n;
+        const bool bad = hd.bad != 0;
+        const int ntap8 = (2 * n + 1 + 7) & ~7;
+#pragma unroll
+        for (int i = 0; i < kRecRegs; ++i)
+            if (tid + i * kBlock < recTotal) sRec[tid + i * kBlock] = L.rreg[i];
+        if (recTotal > kRecRegs * kBlock) {
+            const double* gr = a.recs + (size_t)s * recTotal;
+            for (int i = tid + kRecRegs * kBlock; i < recTotal; i += kBlock) sRec[i] = gr[i];
         }
-        __builtin_amdgcn_sched_barrier(0);             // keep the 8 broadcast reads of one j from piling up
-    }
-    if (tid < kTileSlack) sF[tile_pos(extTight + tid)] = 0.0;
-    __syncthreads();
+        if (tid < tapTotal) sW[tid] = L.tapreg;
+        if (tapTotal > kBlock) {
+            const double* gt = a.taps + (a.taps_shared ? 0 : (size_t)s * tapTotal);
+            for (int i = tid + kBlock; i < tapTotal; i += kBlock) sW[i] = gt[i];
+        }
+#pragma unroll
+        for (int i = 0; i < kTRegs; ++i) {
+            const int idx = tid + i * kBlock;
+            if (idx < VT_NY * VT_NTOT) sT[idx] = L.treg[i];
+        }
+        // the item after this one: the first comes from the grid, the rest from the queue
+        if (tid == 0) *sNext = a.persist ? (int)gridDim.x + (int)atomicAdd(a.queue, 1u) : nItems;
 
-    MCALF_STAMP(4);
-    // ---- 3+4. convolution, continuum, likelihood terms -------------------------------------
-    // Register sliding window: this thread owns outputs base..base+7; per tap one new flux value
-    // and one (broadcast) weight are read from LDS for eight FMAs.
-    double acc = 0.0, nnz = 0.0, c4 = 0.0, c5 = 0.0;
-    const int base = 8 * tid;
-    const bool reduces = (a.mode == kModeLogL || a.mode == kModeChi2);
-    if (base < tlen) {
-        // The data of this thread's 8 pixels are requested now and consumed after the convolution (the
-        // device arrays carry 8 doubles of padding, so the 64-byte reads never need a bounds test).
-        double ob[8], is2[8], lg[8], er[8];
-        if (reduces) {
+        MCALF_STAMP(1);
+        // ---- 2. tau for this thread's pixels ----------------------------------------------------
+        const int shift = a.n_cap - n;
+        __syncthreads();                                   // publishes sRec, sW, sT, sNext
+        const int wNext = __builtin_amdgcn_readfirstlane(*sNext);
+        MCALF_STAMP(2);
+        int buf = 0;
+#ifdef MCALF_ABL_NOLOOP   // ablation builds only (tools/); never defined in the product build
+        const int ncl_run = 0;
+#else
+        const int ncl_run = ncl;
+#endif
+        // kLinesPerSync lines are folded per workgroup barrier (their tables are double-buffered), which
+        // halves the barriers and averages the per-wave core/wing imbalance over more work.
+        for (int cl0 = 0; cl0 < ncl_run; cl0 += kLinesPerSync) {
+#if MCALF_BALANCE_PRIO
+            // Wave priority falls as the workgroup progresses, so of the two workgroups sharing a CU the one
+            // that is behind gets the issue slots.
+            if (4 * cl0 < ncl_run) __builtin_amdgcn_s_setprio(3);
+            else if (4 * cl0 < 2 * ncl_run) __builtin_amdgcn_s_setprio(2);
+            else if (4 * cl0 < 3 * ncl_run) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+#endif
+            double* tabs = sTab + buf * (kLinesPerSync * kTabPad);
+            if (hasCoef) {
+                double Tn[VT_NY];
+#pragma unroll
+                for (int nn = 0; nn < VT_NY; ++nn) Tn[nn] = sT[nn * VT_NTOT + tid];
+#pragma unroll
+                for (int l = 0; l < kLinesPerSync; ++l) {
+                    // no test per line: past the last record the last one is folded again into a slot nobody
+                    // reads, which keeps the group's folds independent chains the scheduler can interleave
+                    const double* rec = sRec + min(cl0 + l, ncl_run - 1) * kRecStride;
+                    tabs[l * kTabPad + coefPos] = fold_coef(Tn, rec[3], coreCoef ? rec[4] : rec[5]);
+                }
+            }
+            __syncthreads();
+            buf ^= 1;
+#pragma unroll 1                 // one copy of the (large) per-line body: keeps the loop inside the instruction cache
+            for (int l = 0; l < kLinesPerSync; ++l) {
+                if (cl0 + l < ncl_run)
+                    eval_line(tabs + l * kTabPad, sRec + (cl0 + l) * kRecStride, nu, tau, nuNode, farNode, segOk);
+            }
+        }
+        if (hd.ngeneral > 0 && ncl_run > 0) eval_general_lines(sRec, ncl, nu, tau);
+        MCALF_STAMP(3);
+#if MCALF_BALANCE_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        // Interpolate the far-wing node sums to the pixels (tau[j] += sum_k W[lane][k] F[segment j][node k]),
+        // then flux = exp(-tau) into the LDS tile.  The node sums travel through the (now dead) folded-table
+        // region, one 64-entry row per wave; the tile holds only the sample's own halo n (<= n_cap).
+        double wrow[VT_INODES];
+        double* sFar = sTab + (tid >> 6) * 64;
+        if (kFarInterp) {
+            __syncthreads();                               // every wave is done reading the folded tables
+            sFar[tid & 63] = farNode;
+#pragma unroll
+            for (int k = 0; k < VT_INODES; ++k) wrow[k] = sWt[k * 64 + (tid & 63)];
+        }
+        const int extTight = tlen + 2 * n;
+#pragma unroll
+        for (int j = 0; j < kPpt; ++j) {
+            double tj = tau[j];
+            if (kFarInterp) {
+                double add = 0.0;
+#pragma unroll
+                for (int k = 0; k < VT_INODES; ++k) add = fma(wrow[k], sFar[8 * j + k], add);
+                tj += add;
+            }
+            const double fl = exp_neg(tj);                 // :377 (product of exp == exp of sum)
+            if (selfHalo) {
+                const int p = tid + j * kBlock;            // pixel index; tile layout [n halo | npix body | n halo]
+                if (p < a.npix) {
+                    sF[tile_pos(p + n)] = fl;
+                    // periodic copies (astropy boundary='wrap'); the JAX path pads with zeros instead (:674)
+                    if (p < n) sF[tile_pos(p + n + a.npix)] = kZeroPad ? 0.0 : fl;
+                    if (p >= a.npix - n) sF[tile_pos(p + n - a.npix)] = kZeroPad ? 0.0 : fl;
+                }
+            } else {
+                const int pos = tid + j * kBlock - shift;
+                if (pos >= 0 && pos < extTight) sF[tile_pos(pos)] = fl;
+            }
+            // keep the 8 broadcast reads of one j from piling up: without the fences the compiler issues the node
+            // sums of all eight segments at once and spills them
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+        }
+        if (tid < kTileSlack) sF[tile_pos(extTight + tid)] = 0.0;
+        __syncthreads();
+
+        MCALF_STAMP(4);
+        // ---- 3+4. convolution, continuum, likelihood terms -------------------------------------
+        // Register sliding window: this thread owns outputs base..base+7; per tap one new flux value
+        // and one (broadcast) weight are read from LDS for eight FMAs.
+        double acc = 0.0, nnz = 0.0, c4 = 0.0, c5 = 0.0;
+        const int base = 8 * tid;
+        const bool reduces = (a.mode == kModeLogL || a.mode == kModeChi2);
+        if (base < tlen) {
+            // The data of this thread's 8 pixels are requested now and consumed after the convolution (the
+            // device arrays carry 8 doubles of padding, so the 64-byte reads never need a bounds test).
+            // The data of this thread's 8 pixels are requested now and consumed after the convolution (the
+            // device arrays carry 8 doubles of padding, so the 64-byte reads never need a bounds test).  The loads
+            // are unconditional on purpose -- model-only calls simply ignore them: defined under `if (reduces)`
+            // the 24 values become phi(undef, load) ranges that the register allocator of the persistent loop
+            // spills one load at a time.
             const size_t o0 = (size_t)(t0 + base);
+            double ob[8], is2[8], lg[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) { ob[m] = a.obj[o0 + m]; is2[m] = a.ispec2[o0 + m]; lg[m] = a.lgis[o0 + m]; }
-            if (a.asymm) {
+            double win[8], top[8];
+            const double* fp = sF + tid;                   // element 8 tid + 8 c + r  ->  fp[r * kPlaneStride + c]
 #pragma unroll
-                for (int m = 0; m < 8; ++m) er[m] = a.err[o0 + m];
+            for (int m = 0; m < 8; ++m) { win[m] = fp[m * kPlaneStride]; top[m] = 0.0; }
+            const double* wp = sW;
+            for (int q0 = 0; q0 < ntap8; q0 += 8) {
+                ++fp;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const double wgt = wp[r];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) top[m] = fma(win[(m + r) & 7], wgt, top[m]);
+                    win[r] = fp[r * kPlaneStride];         // element base + q0 + r + 8
+                }
+                wp += 8;
             }
-        }
-        double win[8], top[8];
-        const double* fp = sF + tid;                   // element 8 tid + 8 c + r  ->  fp[r * kPlaneStride + c]
+            const double ibot = 1.0 / bot;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) { win[m] = fp[m * kPlaneStride]; top[m] = 0.0; }
-        const double* wp = sW;
-        for (int q0 = 0; q0 < ntap8; q0 += 8) {
-            ++fp;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const double w = wp[r];
-#pragma unroll
-                for (int m = 0; m < 8; ++m) top[m] = fma(win[(m + r) & 7], w, top[m]);
-                win[r] = fp[r * kPlaneStride];         // element base + q0 + r + 8
-            }
-            wp += 8;
-        }
-        const double ibot = 1.0 / bot;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int i = base + m;
-            const bool live = i < tlen;
-            const int pix = t0 + i;
-            double mval = kZeroPad ? top[m] : top[m] * ibot;
-            if (kZeroPad && (pix < n || pix >= a.npix - n)) mval = sF[tile_pos(min(i, tlen - 1) + n)];   // :677-681 edge reset
-            mval *= cont;                                                                  // :447 / :683
-            if (bad) mval = NAN;
-            if (a.model && live) a.model[(size_t)s * a.npix + pix] = mval;
-            if (reduces) {
-                const double d = ob[m] - mval;
-                double term = is2[m] * (d * d);
-                if (a.mode == kModeLogL) term = (term - lg[m]) + a.log2pi;                 // :294
-                if (live && !isnan(term)) acc += term;                                     // np.nansum
-                if (a.mode == kModeChi2 && live && mval != 0.0) nnz += 1.0;      // only chi2 asks whether the model is all zero (:241)
-                if (a.asymm) {                                                             // :298-302
-                    const double resid = d / er[m];
-                    if (live && resid > 4.0) c4 += 1.0;
-                    if (live && resid > 5.0) c5 += 1.0;
+            for (int m = 0; m < 8; ++m) {
+                const int i = base + m;
+                const bool live = i < tlen;
+                const int pix = t0 + i;
+                double mval = kZeroPad ? top[m] : top[m] * ibot;
+                if (kZeroPad && (pix < n || pix >= a.npix - n)) mval = sF[tile_pos(min(i, tlen - 1) + n)];   // :677-681 edge reset
+                mval *= cont;                                                                  // :447 / :683
+                if (bad) mval = NAN;
+                if (a.model && live) a.model[(size_t)s * a.npix + pix] = mval;
+                if (reduces) {
+                    const double d = ob[m] - mval;
+                    double term = is2[m] * (d * d);
+                    if (a.mode == kModeLogL) term = (term - lg[m]) + a.log2pi;                 // :294
+                    if (live && !isnan(term)) acc += term;                                     // np.nansum
+                    if (a.mode == kModeChi2 && live && mval != 0.0) nnz += 1.0;      // only chi2 asks whether the model is all zero (:241)
+                    if (a.asymm) {                                                             // :298-302 (rare: loaded here)
+                        const double resid = d / a.err[o0 + m];
+                        if (live && resid > 4.0) c4 += 1.0;
+                        if (live && resid > 5.0) c5 += 1.0;
+                    }
                 }
             }
         }
-    }
-    MCALF_STAMP(5);
-    if (a.mode == kModeModel || a.mode == kModeOneComp) return;
-
-    acc = wave_sum_to_last(acc);
-    if (a.mode == kModeChi2) nnz = wave_sum_to_last(nnz);
-    const int wave = tid >> 6;
-    if ((tid & 63) == 63) { sRed[wave] = acc; sRed[kWaves + wave] = nnz; }
-    double t4 = 0.0, t5 = 0.0;
-    if (a.asymm) {                                   // rare path: two more workgroup sums
-        __syncthreads();
-        t4 = block_sum(c4, sRed + 2 * kWaves, tid);
-        t5 = block_sum(c5, sRed + 2 * kWaves, tid);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double ssum = 0.0, scnt = 0.0;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) { ssum += sRed[w]; scnt += sRed[kWaves + w]; }
-        // LSF wider than the provisioned halo: the model was not computed (the reference would build a longer
-        // kernel); the row must not look like a valid likelihood -> logL = -inf, chi2 = +inf
-        if (bad) { ssum = INFINITY; scnt = 1.0; }
-        MCALF_STAMP(6);
-        MCALF_STAMP(7);
-        if (a.ntiles == 1) {
-            a.out[s] = finalize_value(a.mode, ssum, scnt, a.asymm != 0, t4, t5, a.veto4, a.veto5);
-        } else {
-            double* pr = a.partial + ((size_t)s * a.ntiles + tileIdx) * 4;
-            pr[0] = ssum; pr[1] = scnt; pr[2] = t4; pr[3] = t5;
+        const bool more = wNext < nItems;
+        MCALF_STAMP(5);
+        // The next item's global loads go out here (the pixel data of this item are consumed, so the registers
+        // are free): they land while the reduction and the barrier that ends the item run.
+        __builtin_amdgcn_sched_barrier(0);
+        // (unconditional -- the last item of a workgroup re-requests a valid item it never uses -- so that the
+        // loads REDEFINE every register of L: behind a condition the old values would have to stay alive through
+        // the whole item for the merge)
+        request_item<kZeroPad, kSelfHalo>(a, more ? wNext : w, tid, L);
+        __builtin_amdgcn_sched_barrier(0);
+        if (reduces) {
+            acc = wave_sum_to_last(acc);
+            if (a.mode == kModeChi2) nnz = wave_sum_to_last(nnz);
+            const int wave = tid >> 6;
+            if ((tid & 63) == 63) { sRed[wave] = acc; sRed[kWaves + wave] = nnz; }
         }
+        double t4 = 0.0, t5 = 0.0;
+        if (reduces && a.asymm) {                        // rare path: two more workgroup sums
+            __syncthreads();
+            t4 = block_sum(c4, sRed + 2 * kWaves, tid);
+            t5 = block_sum(c5, sRed + 2 * kWaves, tid);
+        }
+        __syncthreads();                                 // every wave is past its reads of the flux tile and the taps
+        if (reduces && tid == 0) {
+            double ssum = 0.0, scnt = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < kWaves; ++wv) { ssum += sRed[wv]; scnt += sRed[kWaves + wv]; }
+            // LSF wider than the provisioned halo: the model was not computed (the reference would build a longer
+            // kernel); the row must not look like a valid likelihood -> logL = -inf, chi2 = +inf
+            if (bad) { ssum = INFINITY; scnt = 1.0; }
+            MCALF_STAMP(6);
+            MCALF_STAMP(7);
+            if (a.ntiles == 1) {
+                a.out[s] = finalize_value(a.mode, ssum, scnt, a.asymm != 0, t4, t5, a.veto4, a.veto5);
+            } else {
+                double* pr = a.partial + ((size_t)s * a.ntiles + tileIdx) * 4;
+                pr[0] = ssum; pr[1] = scnt; pr[2] = t4; pr[3] = t5;
+            }
+        }
+        if (!more) break;                                // wave-uniform: every wave of the workgroup leaves here
+        w = wNext;
     }
 }
 
@@ -882,6 +957,8 @@ struct mcalf_ctx {
     // block k+1 run in the tail of block k.  chunks_req: 0 = automatic, n = exactly n blocks (1 = off).
     int chunks_req = 0;
     int num_cu = 256;
+    int persist = 1;                    // fused kernel as a persistent grid (MCALF_PERSIST=0: one workgroup per item)
+    unsigned int* d_queue = nullptr;    // [kMaxChunks] work-item queues of the persistent kernel
     hipStream_t aux[kMaxChunks - 1] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxChunks - 1] = {};
     // page-locked staging of the host-pointer entries: parameter rows in, scalars out
@@ -955,7 +1032,8 @@ extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_err, ctx->d_tabs, ctx->d_lines, ctx->d_wtab, ctx->d_segok,
-                    ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds, ctx->d_prior, ctx->d_recs, ctx->d_taps, ctx->d_hdr};
+                    ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds, ctx->d_prior, ctx->d_recs, ctx->d_taps, ctx->d_hdr,
+                    ctx->d_queue};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
@@ -1022,7 +1100,7 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     }
     ctx->ncl_cap = std::max(1, ctx->ncompmax * ctx->nlines + ctx->nfill);
     const size_t fixed_doubles = 2 * (size_t)kLinesPerSync * kTabPad + (size_t)ctx->ncl_cap * kRecStride +
-                                 (2 * (size_t)ctx->n_cap + 8) + 3 * kWaves + 64 * VT_INODES;
+                                 (2 * (size_t)ctx->n_cap + 8) + kRedDoubles + 64 * VT_INODES;
     size_t ext = kExtMax;
     while (ext > 0 && (fixed_doubles + tile_doubles((int)ext)) * sizeof(double) > kLdsBudget) ext -= 64;
     if (ext < 2 * (size_t)ctx->n_cap + 64)
@@ -1165,6 +1243,10 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         hipDeviceProp_t prop;
         HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
         ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_queue, kMaxChunks * sizeof(unsigned int)));
+        HIP_TRY(ctx, hipMemset(ctx->d_queue, 0, kMaxChunks * sizeof(unsigned int)));
+        const char* pe = std::getenv("MCALF_PERSIST");
+        if (pe && *pe) ctx->persist = std::atoi(pe) != 0;
         const char* env = std::getenv("MCALF_CHUNKS");            // 0 / unset: automatic; n: exactly n row blocks
         if (env && *env) {
             const int v = std::atoi(env);
@@ -1259,7 +1341,16 @@ static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0
     a.prior_hi = from_cube ? ctx->d_prior + ctx->ndim : nullptr;
     a.theta_out = (from_cube && d_theta) ? d_theta + (size_t)row0 * ctx->ndim : nullptr;
     a.prior_int = ctx->prior_int;
-    const dim3 grid((unsigned)(nrows * ctx->ntiles)), block(kBlock);
+    a.nitems = (int)(nrows * ctx->ntiles);
+    // Persistent grid = the workgroup slots of the chip (2 per CU: LDS and the 4 waves per SIMD the kernel's
+    // registers allow); correctness does not depend on how many of them are resident at once.  Used once every
+    // slot sees at least four items: measured on MI355X, 8 items per slot (config C) -3.5 % and 160 per slot
+    // (config E) -12 % in kernel time, but 2 per slot (config B) +2 % -- there the queue and the prefetch cost
+    // more than the two workgroup launches they replace, so small launches keep one workgroup per item.
+    const int64_t slots = 2LL * ctx->num_cu;
+    a.persist = (ctx->persist && a.nitems >= 4 * slots) ? 1 : 0;
+    a.queue = ctx->d_queue + chunk;
+    const dim3 grid((unsigned)(a.persist ? slots : a.nitems)), block(kBlock);
     if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX)
         hipLaunchKernelGGL(mcalf_sample_kernel<true>, dim3((unsigned)nrows), dim3(64), 0, stream, a, (long)nrows);
     else
@@ -1286,15 +1377,13 @@ static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0
     return MCALF_OK;
 }
 
-// Row blocks a batch is issued in: the caller's request, or automatically two blocks once the batch fills the
-// chip several times over (each workgroup slot then sees >= 2 workgroups per block, so the split costs no
-// occupancy and the second block's set-up kernel + first wave of workgroups run in the tail of the first).
+// Row blocks a *_device batch is issued in.  Automatic = ONE: measured on MI355X (config C, 4096 live points), every
+// extra block costs ~20 us of cross-stream event traffic and buys nothing, because the persistent fused kernel
+// leaves no launch tail for the next block to fill (0.267 / 0.287 / 0.309 / 0.327 ms per batch with 1 / 2 / 3 / 4
+// blocks).  The knob stays for callers that want to interleave their own work, and for the host-pointer entry,
+// where blocks overlap the PCIe copies with the kernels (run_host_pipelined).
 static int pick_chunks(const mcalf_ctx* ctx, int64_t batch) {
-    int n = ctx->chunks_req;
-    if (n <= 0) {
-        const int64_t wgs = batch * ctx->ntiles, slots = 2LL * ctx->num_cu;
-        n = (wgs >= 4 * slots) ? 2 : 1;
-    }
+    int n = ctx->chunks_req > 0 ? ctx->chunks_req : 1;
     if (n > kMaxChunks) n = kMaxChunks;
     if ((int64_t)n > batch) n = (int)batch;
     return n < 1 ? 1 : n;
@@ -1318,7 +1407,7 @@ static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int
                   double* d_out, double* d_model, hipStream_t stream, bool from_cube = false,
                   double* d_theta = nullptr) {
     if (batch == 0) return MCALF_OK;
-    if (batch < 0 || batch * (int64_t)ctx->ntiles > 0x7fffffffLL)
+    if (batch < 0 || batch * (int64_t)ctx->ntiles > 0x7fff0000LL)
         return set_err(ctx, MCALF_ERR_RANGE, "batch %lld too large", (long long)batch);
     const bool reduces = (mode == kModeLogL || mode == kModeChi2);
     int rc;

@@ -38,6 +38,7 @@ def test_row_blocks_do_not_change_results(cfg, n):
             for _ in range(2):                      # twice: the second call reuses streams, events, workspaces
                 assert np.array_equal(_device_logl(fit, dP, n), whole)
         fit.set_chunks(0)
+        assert fit.chunks_for(n) == 1
         assert np.array_equal(_device_logl(fit, dP, n), whole)
         # host-pointer entry: pageable arrays (staged), page-locked arrays (direct DMA), every block count
         for k in (0, 1, 2, 5):
