@@ -38,10 +38,10 @@ constexpr int kRecStride = 8;           // doubles per (component,line) record i
 constexpr int kTabPad = VT_NTOT + 3;    // folded table in LDS: zone0 / zoneF shifted to stay 16-B aligned
 constexpr int kZ0Lds = VT_Z0_OFF + 1;
 constexpr int kZFLds = VT_ZF_OFF + 2;
-#ifndef MCALF_LINES_PER_SYNC
-#define MCALF_LINES_PER_SYNC 4
-#endif
-constexpr int kLinesPerSync = MCALF_LINES_PER_SYNC;
+// Lines folded per workgroup barrier of the component loop: 4 or 5, chosen per context (whichever needs fewer
+// barriers for the context's largest line count; measured on MI355X: config C, 20-24 lines, -0.8 % with 5;
+// config E, 16 lines, +1.3 % with 5).
+constexpr int kLinesPerSyncMax = 5;
 static_assert(kBlock == 64 * VT_INODES, "one interpolation weight per thread");
 static_assert(VT_NTOT <= 512 && (kZ0Lds % 2) == 0 && (kZFLds % 2) == 0 && (kTabPad % 2) == 0, "LDS table layout");
 constexpr int kRedDoubles = 3 * kWaves + 2;   // per-wave partials (sum, count, scratch) + the next work-item index
@@ -245,18 +245,12 @@ __device__ inline void build_line_record(double* rec, double logN, double z, dou
     }
 }
 
-#ifdef MCALF_STAMPS   // diagnostic builds only (tools/): per-workgroup phase timestamps
+#ifdef MCALF_STAMPS   // diagnostic builds only (tools/): per-work-item phase timestamps (`w` = the item index in scope)
 __device__ unsigned long long g_stamps[8192 * 8];
 __device__ unsigned long long g_dbg[4];   // [0] interpolated segments, [1] segments seen
-#define MCALF_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (k)] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#define MCALF_STAMP(k) do { if (threadIdx.x == 0 && w < 8192) g_stamps[w * 8 + (k)] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define MCALF_STAMP(k) do { } while (0)
-#endif
-#ifdef MCALF_STAMPS
-__device__ unsigned long long g_stamps2[8192 * 8];
-#define MCALF_SUB(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps2[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define MCALF_SUB(k) do { } while (0)
 #endif
 
 // acc += a * b and acc += a with the accumulator tied to its register: without the tie the compiler
@@ -578,7 +572,7 @@ __device__ __forceinline__ void request_item(const KArgs& a, int w, int tid, Ite
 // requested before the likelihood terms of the current one and written to LDS behind the barrier that ends it.
 // Every wave leaves the item loop at the same item count (the queue value is broadcast through LDS), so no wave
 // is ever left behind a barrier.
-template <bool kZeroPad, bool kSelfHalo>
+template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync>
 __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {
     extern __shared__ __align__(16) double smem[];
     double* sTab = smem;                                   // 2 x kLinesPerSync folded tables
@@ -736,30 +730,42 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             for (int k = 0; k < VT_INODES; ++k) wrow[k] = sWt[k * 64 + (tid & 63)];
         }
         const int extTight = tlen + 2 * n;
+        // Two pixels per round: their interpolation sums and exponentials are independent chains the scheduler
+        // interleaves (one pixel at a time the phase is bound by the latency of a single ~35-instruction chain).
+        // The fences keep it at two: without them the compiler issues the node sums of all eight segments at
+        // once and spills them.
+        static_assert(kPpt % 2 == 0, "pixels are processed in pairs");
 #pragma unroll
-        for (int j = 0; j < kPpt; ++j) {
-            double tj = tau[j];
-            if (kFarInterp) {
-                double add = 0.0;
+        for (int j0 = 0; j0 < kPpt; j0 += 2) {
+            double fl[2];
 #pragma unroll
-                for (int k = 0; k < VT_INODES; ++k) add = fma(wrow[k], sFar[8 * j + k], add);
-                tj += add;
-            }
-            const double fl = exp_neg(tj);                 // :377 (product of exp == exp of sum)
-            if (selfHalo) {
-                const int p = tid + j * kBlock;            // pixel index; tile layout [n halo | npix body | n halo]
-                if (p < a.npix) {
-                    sF[tile_pos(p + n)] = fl;
-                    // periodic copies (astropy boundary='wrap'); the JAX path pads with zeros instead (:674)
-                    if (p < n) sF[tile_pos(p + n + a.npix)] = kZeroPad ? 0.0 : fl;
-                    if (p >= a.npix - n) sF[tile_pos(p + n - a.npix)] = kZeroPad ? 0.0 : fl;
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = j0 + jj;
+                double tj = tau[j];
+                if (kFarInterp) {
+                    double add = 0.0;
+#pragma unroll
+                    for (int k = 0; k < VT_INODES; ++k) add = fma(wrow[k], sFar[8 * j + k], add);
+                    tj += add;
                 }
-            } else {
-                const int pos = tid + j * kBlock - shift;
-                if (pos >= 0 && pos < extTight) sF[tile_pos(pos)] = fl;
+                fl[jj] = exp_neg(tj);                      // :377 (product of exp == exp of sum)
             }
-            // keep the 8 broadcast reads of one j from piling up: without the fences the compiler issues the node
-            // sums of all eight segments at once and spills them
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = j0 + jj;
+                if (selfHalo) {
+                    const int p = tid + j * kBlock;        // pixel index; tile layout [n halo | npix body | n halo]
+                    if (p < a.npix) {
+                        sF[tile_pos(p + n)] = fl[jj];
+                        // periodic copies (astropy boundary='wrap'); the JAX path pads with zeros instead (:674)
+                        if (p < n) sF[tile_pos(p + n + a.npix)] = kZeroPad ? 0.0 : fl[jj];
+                        if (p >= a.npix - n) sF[tile_pos(p + n - a.npix)] = kZeroPad ? 0.0 : fl[jj];
+                    }
+                } else {
+                    const int pos = tid + j * kBlock - shift;
+                    if (pos >= 0 && pos < extTight) sF[tile_pos(pos)] = fl[jj];
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::: "memory");
         }
@@ -927,7 +933,7 @@ struct mcalf_ctx {
     int asymm = 0;
     double veto4 = 0, veto5 = 0;
     // geometry
-    int n_cap = 0, tile = 0, ntiles = 0, ncl_cap = 0, jax_half = 0, selfhalo = 0;
+    int n_cap = 0, tile = 0, ntiles = 0, ncl_cap = 0, jax_half = 0, selfhalo = 0, lps = 4;
     size_t lds_bytes = 0;
     // device buffers
     double *d_nu = nullptr, *d_obj = nullptr, *d_ispec2 = nullptr, *d_lgis = nullptr, *d_err = nullptr, *d_tabs = nullptr;
@@ -1048,6 +1054,18 @@ extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     delete ctx;
 }
 
+// The eight instantiations of the fused kernel: (JAX semantics, self-halo tile, lines per barrier).
+static const void* fused_kernel_ptr(bool jax, bool selfhalo, int lps) {
+#define MCALF_K(J, S, L) reinterpret_cast<const void*>(&mcalf_fused_kernel<J, S, L>)
+    if (lps == 5) {
+        if (jax) return selfhalo ? MCALF_K(true, true, 5) : MCALF_K(true, false, 5);
+        return selfhalo ? MCALF_K(false, true, 5) : MCALF_K(false, false, 5);
+    }
+    if (jax) return selfhalo ? MCALF_K(true, true, 4) : MCALF_K(true, false, 4);
+    return selfhalo ? MCALF_K(false, true, 4) : MCALF_K(false, false, 4);
+#undef MCALF_K
+}
+
 static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     if (!sp) return set_err(ctx, MCALF_ERR_INVALID, "spec is NULL");
     if (sp->npix <= 0 || !sp->wl || !sp->flux || !sp->err)
@@ -1099,7 +1117,13 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         ctx->n_cap = (rmax > sp->velstep) ? (int)std::ceil(kKernelReach * sigma_max) : 0;
     }
     ctx->ncl_cap = std::max(1, ctx->ncompmax * ctx->nlines + ctx->nfill);
-    const size_t fixed_doubles = 2 * (size_t)kLinesPerSync * kTabPad + (size_t)ctx->ncl_cap * kRecStride +
+    // lines per barrier: 5 when that saves a barrier at the context's largest line count, else 4
+    ctx->lps = ((ctx->ncl_cap + 4) / 5 < (ctx->ncl_cap + 3) / 4) ? 5 : 4;
+    if (const char* e = std::getenv("MCALF_LINES_PER_SYNC")) {
+        const int v = std::atoi(e);
+        if (v == 4 || v == 5) ctx->lps = v;
+    }
+    const size_t fixed_doubles = 2 * (size_t)ctx->lps * kTabPad + (size_t)ctx->ncl_cap * kRecStride +
                                  (2 * (size_t)ctx->n_cap + 8) + kRedDoubles + 64 * VT_INODES;
     size_t ext = kExtMax;
     while (ext > 0 && (fixed_doubles + tile_doubles((int)ext)) * sizeof(double) > kLdsBudget) ext -= 64;
@@ -1232,10 +1256,10 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_wtab, sizeof(VT_INTERP_W_HOST)));
     HIP_TRY(ctx, hipMemcpy(ctx->d_wtab, VT_INTERP_W_HOST, sizeof(VT_INTERP_W_HOST), hipMemcpyHostToDevice));
     // more than 64 KiB of dynamic LDS needs the attribute (2 workgroups x 78 KiB fit the 160 KiB of a CU)
-    const void* kernels[] = {reinterpret_cast<const void*>(&mcalf_fused_kernel<false, false>),
-                             reinterpret_cast<const void*>(&mcalf_fused_kernel<false, true>),
-                             reinterpret_cast<const void*>(&mcalf_fused_kernel<true, false>),
-                             reinterpret_cast<const void*>(&mcalf_fused_kernel<true, true>)};
+    const void* kernels[] = {fused_kernel_ptr(false, false, 4), fused_kernel_ptr(false, true, 4),
+                             fused_kernel_ptr(true, false, 4),  fused_kernel_ptr(true, true, 4),
+                             fused_kernel_ptr(false, false, 5), fused_kernel_ptr(false, true, 5),
+                             fused_kernel_ptr(true, false, 5),  fused_kernel_ptr(true, true, 5)};
     for (const void* k : kernels)
         HIP_TRY(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -1358,11 +1382,11 @@ static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0
     HIP_TRY(ctx, hipGetLastError());
     const bool timed = timed_ok && ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used], stream));
-    const bool jaxmode = ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX;
-    if (jaxmode && ctx->selfhalo) hipLaunchKernelGGL((mcalf_fused_kernel<true, true>), grid, block, ctx->lds_bytes, stream, a);
-    else if (jaxmode) hipLaunchKernelGGL((mcalf_fused_kernel<true, false>), grid, block, ctx->lds_bytes, stream, a);
-    else if (ctx->selfhalo) hipLaunchKernelGGL((mcalf_fused_kernel<false, true>), grid, block, ctx->lds_bytes, stream, a);
-    else hipLaunchKernelGGL((mcalf_fused_kernel<false, false>), grid, block, ctx->lds_bytes, stream, a);
+    {
+        void* kargs[] = {(void*)&a};
+        HIP_TRY(ctx, hipLaunchKernel(fused_kernel_ptr(ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX, ctx->selfhalo != 0, ctx->lps),
+                                     grid, block, kargs, ctx->lds_bytes, stream));
+    }
     HIP_TRY(ctx, hipGetLastError());
     if (timed) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], stream));
@@ -1721,9 +1745,6 @@ extern "C" int mcalf_voigt_hjerting_nodes(const double* x, const double* y, int6
 #ifdef MCALF_STAMPS
 extern "C" int mcalf_diag_read_stamps(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_stamps), (size_t)n * sizeof(unsigned long long));
-}
-extern "C" int mcalf_diag_read_stamps2(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_stamps2), (size_t)n * sizeof(unsigned long long));
 }
 extern "C" int mcalf_diag_read_dbg(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_dbg), 4 * sizeof(unsigned long long));

@@ -28,9 +28,9 @@ def rep(a, b):
     s = s.replace(a, b, 1)
 
 
-rep("template <bool kZeroPad, bool kSelfHalo>\n__global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {",
+rep("template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync>\n__global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {",
     "__device__ unsigned long long g_acc[8192 * 32];\n#define CLK() __builtin_amdgcn_s_memtime()\n"
-    "template <bool kZeroPad, bool kSelfHalo>\n__global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {\n"
+    "template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync>\n__global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {\n"
     "    unsigned long long accFold = 0, accBar = 0, accNode = 0, accDirect = 0;")
 rep("                                          double& farNode, unsigned long long segOk) {\n    const double A = rec[0], B = rec[1], x2c = rec[2];",
     "                                          double& farNode, unsigned long long segOk, unsigned long long& accNode, unsigned long long& accDirect) {\n"
@@ -41,14 +41,14 @@ rep("#pragma unroll\n    for (int j = 0; j < kPpt; ++j) {\n        if (__builtin
 rep("        fmac_inplace(tau[j], t, P);\n    }\n}", "        fmac_inplace(tau[j], t, P);\n    }\n    accDirect += __builtin_amdgcn_s_memtime() - c1;\n}")
 rep("eval_line(tabs + l * kTabPad, sRec + (cl0 + l) * kRecStride, nu, tau, nuNode, farNode, segOk);",
     "eval_line(tabs + l * kTabPad, sRec + (cl0 + l) * kRecStride, nu, tau, nuNode, farNode, segOk, accNode, accDirect);")
-rep("        double* tabs = sTab + buf * (kLinesPerSync * kTabPad);\n        if (hasCoef) {",
-    "        const unsigned long long f0 = CLK();\n        double* tabs = sTab + buf * (kLinesPerSync * kTabPad);\n        if (hasCoef) {")
-rep("        __syncthreads();\n        buf ^= 1;",
-    "        const unsigned long long f1 = CLK();\n        __syncthreads();\n        const unsigned long long f2 = CLK();\n"
-    "        accFold += f1 - f0; accBar += f2 - f1;\n        buf ^= 1;")
-rep("    MCALF_STAMP(3);",
-    "    MCALF_STAMP(3);\n    if ((threadIdx.x & 63) == 0 && blockIdx.x < 8192) { unsigned long long* q = g_acc + blockIdx.x * 32 + 4 * (threadIdx.x >> 6); "
-    "q[0] = accFold; q[1] = accBar; q[2] = accNode; q[3] = accDirect; }")
+rep("            double* tabs = sTab + buf * (kLinesPerSync * kTabPad);\n            if (hasCoef) {",
+    "            const unsigned long long f0 = CLK();\n            double* tabs = sTab + buf * (kLinesPerSync * kTabPad);\n            if (hasCoef) {")
+rep("            __syncthreads();\n            buf ^= 1;",
+    "            const unsigned long long f1 = CLK();\n            __syncthreads();\n            const unsigned long long f2 = CLK();\n"
+    "            accFold += f1 - f0; accBar += f2 - f1;\n            buf ^= 1;")
+rep("        MCALF_STAMP(3);",
+    "        MCALF_STAMP(3);\n        if ((threadIdx.x & 63) == 0 && w < 8192) { unsigned long long* q = g_acc + w * 32 + 4 * (threadIdx.x >> 6); "
+    "q[0] = accFold; q[1] = accBar; q[2] = accNode; q[3] = accDirect; }\n        accFold = accBar = accNode = accDirect = 0;")
 rep('extern "C" int mcalf_diag_read_dbg',
     'extern "C" int mcalf_diag_read_acc(unsigned long long* out, int n) {\n'
     '    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_acc), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;\n}\n'

@@ -31,9 +31,9 @@ buf = (C.c_ulonglong * (n * 8))()
 lib.mcalf_diag_read_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.mcalf_diag_read_stamps(buf, n * 8) == 0
 st = np.array(buf, dtype=np.uint64).reshape(n, 8).astype(np.int64)
-names = ["start", "setup(decode,records,taps)", "nu loads", "component loop", "exp+flux store", "conv+terms", "reduce"]
+names = ["start", "item set-up (LDS writes)", "barrier", "component loop", "exp+flux store", "conv+terms+prefetch", "reduce"]
 print("workgroups", n)
-for k in range(2, 7):
+for k in range(1, 7):
     d = st[:, k] - st[:, k - 1]
     print("%-28s mean %9.0f  median %9.0f  max %9.0f cycles" % (names[k], d.mean(), np.median(d), d.max()))
 # global timeline from s_memrealtime (100 MHz): stamps 0 (start) and 7 (end)
@@ -65,18 +65,6 @@ try:
     lib.mcalf_diag_read_dbg(dbg)
     print("far-wing interpolation: %d of %d (line, segment) pairs interpolated (%.1f %%); segOk bits per 8 = %.2f"
           % (dbg[0], dbg[1], 100.0 * dbg[0] / max(1, dbg[1]), 8.0 * dbg[2] / max(1, dbg[1])))
-except AttributeError:
-    pass
-
-try:
-    buf2 = (C.c_ulonglong * (n * 8))()
-    lib.mcalf_diag_read_stamps2.argtypes = [C.c_void_p, C.c_int]
-    lib.mcalf_diag_read_stamps2(buf2, n * 8)
-    s2 = np.array(buf2, dtype=np.uint64).reshape(n, 8).astype(np.int64)
-    nm = ["", "T/weight loads issued", "decode + records", "taps + T store", "nu loads issued", "barrier wait"]
-    for k in range(1, 6):
-        d = s2[:, k] - s2[:, k - 1]
-        print("setup: %-24s mean %7.0f  round1 %7.0f  round2 %7.0f cycles" % (nm[k], d.mean(), d[first].mean(), d[~first].mean()))
 except AttributeError:
     pass
 
