@@ -6,8 +6,8 @@ switch `from mcalf.routines import hires_fitter` to this module unchanged.  Ever
 likelihood / model method is a batch-of-one call into the HIP library
 (`libmcalf_hip.so`); `loglike_batch` / `model_batch` are the vectorised entries.
 
-What is NOT here (out of scope): INI parsing, solver dispatch,
-plotting, chain readers.  linetools is replaced by an explicit `linepars=` argument
+What is NOT here (out of scope): solver dispatch, plotting, chain
+readers (`pc_analyzer`, `get_parnames`), the prior log-density (`lnprior`, which no solver branch calls).  linetools is replaced by an explicit `linepars=` argument
 plus a tiny built-in table (`LINE_TABLE`).
 """
 from __future__ import annotations
@@ -208,7 +208,9 @@ class als_fitter:
         jax = (self.conv_mode == "jax")
         # numpy path: float(max(specres)) (:415-417); JAX path: specres[0] (:572)
         sp.specres_fixed = float(self.specres[0]) if jax else float(max(self.specres))
-        sp.specres_max = float(max(self.specres))
+        # LSF reach: numpy path max(specres); the JAX path sizes its fixed kernel grid from res_lims[1] when the
+        # resolution is free (hires_fitter.py:549-550: the SECOND entry, not the maximum) and from max otherwise
+        sp.specres_max = float(self.specres[1]) if (jax and self.freespecres) else float(max(self.specres))
         sp.contval_fixed = float(self.contval[0])
         sp.conv_mode = _lib.MCALF_CONV_SAME_EDGE_JAX if jax else _lib.MCALF_CONV_WRAP_NUMPY
         sp.device = int(device)
@@ -225,6 +227,10 @@ class als_fitter:
         self.info = info
 
     def close(self):
+        twin = getattr(self, "_twin", None)
+        if twin is not None:
+            twin.close()
+            self._twin = None
         if self._ctx is not None:
             self._lib.mcalf_destroy(self._ctx)
             self._ctx = None
@@ -295,22 +301,6 @@ class als_fitter:
             self._ctx, cubes.ctypes.data_as(pd), cubes.shape[0],
             theta.ctypes.data_as(pd) if return_theta else None, logL.ctypes.data_as(pd)), self._ctx)
         return (theta, logL) if return_theta else logL
-
-    def lnprior(self, p):
-        """Log prior (hires_fitter.py:218-234): -inf outside the box; inside, the sum of the Gaussian priors
-        given as (mean, sigma) string pairs in `Gpriors` ('none' = flat), 0 without any."""
-        p = np.asarray(p, dtype=float)
-        if np.any(p < self._lo) or np.any(p > self._hi) or np.any(np.isnan(p)):
-            return -np.inf
-        total = 0
-        if self.Gpriors is not None:
-            for k, value in enumerate(p):
-                mean, sigma = self.Gpriors[2 * k], self.Gpriors[2 * k + 1]
-                if mean == 'none' or sigma == 'none':
-                    continue
-                mean, sigma = float(mean), float(sigma)
-                total += -0.5 * (((value - mean) / sigma) ** 2 + np.log(2. * np.pi * sigma ** 2))
-        return total
 
     # ------------------------------------------------------------------ batched entries
     def _rows(self, P, width):
@@ -419,30 +409,45 @@ class als_fitter:
         """hires_fitter.py:394-406."""
         return self.onecomp_batch([specresolution, _scalar(continuum), N, z, b], fill=True)[0]
 
-    def calc_w(self, p, lineid=0):
-        """Rest-frame equivalent width of line `lineid` summed over the ACTIVE components
-        (hires_fitter.py:467-491).  The reference slices `p[3*comp+startind : +3]` (:482), i.e. it
-        forgets the ncomp slot and loops over ncompmax; this follows the parameter layout of
-        reconstruct_spec (:431) instead -- a deliberate deviation from a routine no solver calls."""
+    def calc_w(self, p, lineid=0, reference_indexing=True):
+        """Rest-frame equivalent width of line `lineid` (hires_fitter.py:467-491).
+
+        `reference_indexing=True` (default) reproduces the reference AS WRITTEN: it loops over all `ncompmax`
+        slots and slices `p[3*comp+startind : 3*comp+3+startind]` (:482), i.e. it starts at the ncomp slot
+        instead of one past it, so the triples it integrates are (ncomp, N1, z1), (b1, N2, z2), ... read as
+        (N, z, b).  `reference_indexing=False` follows the parameter layout of reconstruct_spec (:431) over the
+        ACTIVE components -- what the routine evidently intends.  No solver calls either."""
         p = np.asarray(p, dtype=float)
         cont = (p[1] if self.freespecres else p[0]) if self.freecont else _scalar(self.contval)
-        nc = min(max(int(p[self.startind]), 0), self.ncompmax)
+        if reference_indexing:
+            nc, first = int(self.ncompmax), self.startind
+        else:
+            nc, first = min(max(int(p[self.startind]), 0), self.ncompmax), self.startind + 1
         if nc == 0:
-            return 0.0
-        comps = p[self.startind + 1: self.startind + 1 + 3 * nc].reshape(nc, 3)            # (N, z, b)
-        Q = np.column_stack([np.zeros(nc), np.full(nc, cont), comps])                      # R = 0: unconvolved
+            return 0 if reference_indexing else 0.0
+        comps = p[first: first + 3 * nc].reshape(nc, 3)                                    # read as (N, z, b)
+        Q = np.column_stack([np.zeros(nc), np.full(nc, cont), comps])                      # R = 0: unconvolved (:483)
         absorption = self.onecomp_batch(Q, line=lineid)
         dlambda = np.diff(self.obj_wl)
         dlambda = np.insert(dlambda, 0, dlambda[0])
-        w = np.sum((1 - (absorption / cont)) * dlambda, axis=1)
-        return float(np.sum(w / (1 + comps[:, 1])))
+        w = np.sum((1 - (absorption / cont)) * dlambda, axis=1)                            # :488
+        return float(np.sum(w / (1 + comps[:, 1])))                                        # :489
 
-    def calc_N(self, p):
-        """Total column density log10(sum 10**N) of the slots with z < 10 (the z cut drops the
-        fillers, which sit at z ~ 24).  hires_fitter.py:493-505 strides from `startind` (:499-500),
-        i.e. it reads (ncomp, b1, b2, ...) as N and (N1, N2, ...) as z and always returns -inf for
-        real columns; this strides from the first N slot, as the layout (:431) implies."""
+    def calc_N(self, p, reference_indexing=True):
+        """Total column density log10(sum 10**N) of the slots with z < 10 (hires_fitter.py:493-505).
+
+        `reference_indexing=True` (default) evaluates the reference's own expressions: `p[startind::3]` as N and
+        `p[startind+1::3]` as z (:499-500) -- strides that start at the ncomp slot, so "N" is (ncomp, b1, b2, ...)
+        and "z" is (N1, N2, ...); the two differ in length by one for every valid layout and numpy raises the same
+        IndexError the reference raises.  `reference_indexing=False` strides from the first N slot, as the layout
+        (:431) implies; the z cut then drops the fillers, which sit at z ~ 24."""
         p = np.asarray(p, dtype=float)
+        if reference_indexing:
+            allN = p[self.startind::3]
+            allz = p[self.startind + 1::3]
+            okN = (allz < 10)
+            allN = 10 ** allN[okN]
+            return np.log10(np.sum(allN))
         allN = p[self.startind + 1::3]
         allz = p[self.startind + 2::3]
         n = min(allN.size, allz.size)
@@ -459,12 +464,64 @@ class als_fitter:
                    wrangefill=run_params['wrangefill'], coldef=run_params['coldef'],
                    Asymmlike=run_params['asymmlike'], **extra)
 
-    def get_jax_likelihood(self):
-        """hires_fitter.py:521-695 returns a JAX-traceable closure.  JAX is not a dependency
-        of this package (and the north-star excludes JAX dispatch); use `conv_mode='jax'`
-        with `loglike_batch` for that path's semantics evaluated by the HIP kernel."""
-        raise ImportError("JAX is not available; construct als_fitter(..., conv_mode='jax') and call "
-                          "loglike_batch / lnlhood_dy instead")
+    def get_jax_likelihood(self, use_jax=None):
+        """Counterpart of the closure hires_fitter.py:521-695 returns (`log_likelihood` of cli.py:237,256):
+        `log_likelihood(p) -> float32 scalar` with the JAX path's semantics -- theta in float32, floor() on the
+        ncomp slot (:616), one exp of the summed optical depth (:663), LSF kernel on the fixed grid of the
+        largest resolution (:549-560), zero-padded 'same' convolution that is always applied (:674), first / last
+        half_size pixels reset to the unconvolved model (:677-681) -- evaluated by the HIP kernel
+        (`conv_mode='jax'` context) in float64 and rounded to float32 on return.  float32 arithmetic itself is
+        not reproduced: the reference's own float32 path loses 0.6 in logL to cancellation.
+
+        The closure is batch-capable: `p` of shape [..., ndim] gives float32 [...].  With JAX installed (and
+        `use_jax` not False) it is wrapped in `jax.pure_callback`, so it can be traced, jitted and vmapped by
+        jaxns exactly like the reference's closure; without JAX it is the plain host function.  `use_jax=True`
+        raises ImportError when JAX is absent, as the reference does (:523-524)."""
+        twin = self if self.conv_mode == "jax" else self._jax_twin()
+        ndim = self.ndim
+
+        def host_loglike(p):
+            p32 = np.asarray(p, dtype=np.float32)                        # jaxns hands float32 live points (:529-536)
+            if p32.shape[-1:] != (ndim,):
+                raise ValueError(f"parameter vectors must have {ndim} entries")
+            rows = np.ascontiguousarray(p32.reshape(-1, ndim), dtype=np.float64)
+            ll = twin.loglike_batch(rows).astype(np.float32)
+            return ll.reshape(p32.shape[:-1]) if p32.ndim > 1 else ll.reshape(())[()]
+
+        try:
+            if use_jax is False:
+                raise ImportError
+            import jax
+            import jax.numpy as jnp
+        except ImportError:
+            if use_jax:
+                raise ImportError("JAX is not available.")
+            host_loglike.fitter = twin
+            return host_loglike
+
+        def log_likelihood(p):                                           # pragma: no cover - needs JAX
+            p = jnp.asarray(p, dtype=jnp.float32)
+            shape = jax.ShapeDtypeStruct(p.shape[:-1], jnp.float32)
+            return jax.pure_callback(lambda q: np.asarray(host_loglike(q), dtype=np.float32).reshape(q.shape[:-1]),
+                                     shape, p, vmap_method="expand_dims")
+        log_likelihood.fitter = twin
+        log_likelihood.host = host_loglike
+        return log_likelihood
+
+    def _jax_twin(self):
+        """A second context over the same arrays with the JAX path's boundary semantics (kept for the
+        lifetime of this object)."""
+        if getattr(self, "_twin", None) is None:
+            self._twin = als_fitter(
+                None, self.fitrange, self.fitlines, [self.ncompmin, self.ncompmax], nfill=self.nfill,
+                specres=self.specres, contval=self.contval, Nrange=list(self.N_lims), brange=list(self.b_lims),
+                zrange=[z for lim in self.z_lims for z in lim], Nrangefill=list(self.N_lims_fill),
+                brangefill=list(self.b_lims_fill),
+                wrangefill=[(1 + z) * self.linefill["wrest"] for lim in self.z_lims_fill for z in lim] or None,
+                Asymmlike=False, spectrum=(self.obj_wl, self.obj, self.obj_noise),
+                linepars=[(lp["wrest"], lp["f"], lp["gamma"]) for lp in self.linepars], velstep=self.velstep,
+                conv_mode="jax", device=self.info.device, gauss_cdf=self.gauss_cdf)
+        return self._twin
 
 
 def _scalar(v):
@@ -475,49 +532,12 @@ def _scalar(v):
 # Module-level helpers of the reference module (usable without an als_fitter instance)
 # ---------------------------------------------------------------------------------------------
 
-def get_parnames(ncomp, cont=False):
-    """hires_fitter.py:749-759."""
-    names = ['Cont'] if cont else []
-    for i in range(1, ncomp + 1):
-        names += ['N%d' % i, 'z%d' % i, 'b%d' % i]
-    return names
-
-
 def write_equal_weights(path, logl, samples):
-    """Chain file in the layout the CLI writes and `pc_analyzer` reads (cli.py:314-325):
+    """Chain file in the layout the CLI writes (cli.py:314-325):
     columns [weight = 1, -2 logL, parameters...]."""
     logl = np.asarray(logl, dtype=float).reshape(-1)
     samples = np.asarray(samples, dtype=float).reshape(logl.size, -1)
     np.savetxt(path, np.column_stack([np.ones_like(logl), -2.0 * logl, samples]))
-
-
-def pc_analyzer(filesbasename, return_sorted=True):
-    """Read `<base>.stats` (log(Z) line) and `<base>_equal_weights.txt`; optionally sort each
-    sample's active components by redshift and blank the inactive ones (hires_fitter.py:704-747)."""
-    lnz = lnz_err = None
-    with open(filesbasename + '.stats') as fh:
-        for line in fh:
-            if line.startswith('log(Z)'):
-                items = line.split()
-                lnz, lnz_err = float(items[2]), float(items[4])
-    allsamples = np.loadtxt(filesbasename + '_equal_weights.txt', ndmin=2)
-    lhoodsamples = -0.5 * allsamples[:, 1]
-    post = allsamples[:, 2:]
-    if not return_sorted:
-        return lnz, lnz_err, lhoodsamples, post
-    print('Sorting components in redshift')
-    out = post.copy()
-    start = (post.shape[1] - 1) % 3                      # index of the ncomp slot (:728)
-    for row_in, row_out in zip(post, out):
-        nc = int(row_in[start])
-        end = start + 1 + 3 * nc
-        row_in[end:] = 99                                # the reference overwrites its input too (:736)
-        triples = row_in[start + 1:end].reshape(nc, 3)
-        order = np.argsort(triples[:, 1])
-        row_out[start + 1:end] = triples[order].reshape(-1)
-        row_out[end:] = np.nan                           # 99 -> nan (:743)
-    out[out == 99] = np.nan
-    return lnz, lnz_err, lhoodsamples, out
 
 
 _BOOL = {'True': True, 'False': False}

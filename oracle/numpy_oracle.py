@@ -293,8 +293,9 @@ def model_batch(prob: Problem, P: np.ndarray, targonly: bool = False) -> np.ndar
 # ----------------------------------------------------------------------------------
 
 def jax_half_size(prob: Problem) -> int:
-    """hires_fitter.py:549-559."""
-    max_res = float(np.max(prob.specres))
+    """hires_fitter.py:549-559: `res_lims[1]` -- the SECOND entry of specres, not its maximum -- when the
+    resolution is free (:550), `np.max(specres)` otherwise (:552-555)."""
+    max_res = float(np.asarray(prob.specres, dtype=float)[1]) if prob.freespecres else float(np.max(prob.specres))
     sigma_max = (max_res / 2.354820) / prob.velstep
     return int(np.ceil(np.float32(3.0348 * sigma_max)))
 
@@ -455,6 +456,39 @@ def jax_loglike_f32(prob: Problem, p, dt=np.float32) -> float:
 # ----------------------------------------------------------------------------------
 # Analysis helpers ("next" rows)
 # ----------------------------------------------------------------------------------
+
+def calc_w_reference(prob: Problem, p, lineid: int = 0) -> float:
+    """hires_fitter.py:467-491 AS WRITTEN: every one of the ncompmax slots, sliced from `3*comp + startind`
+    (:482) -- one short of the layout reconstruct_spec uses (:431), so the triples are (ncomp, N1, z1),
+    (b1, N2, z2), ... read as (N, z, b)."""
+    p = np.asarray(p, dtype=float)
+    if prob.freecont:                                            # :473-479
+        cont = p[1] if prob.freespecres else p[0]
+    else:
+        cont = np.asarray(prob.contval, dtype=float)             # `self.contval`, a length-1 sequence
+    wrest, f, gam = prob.lines[lineid]
+    Wtot = 0
+    for comp in range(prob.ncompmax):                            # :481
+        _N, _z, _b = p[3 * comp + prob.startind: 3 * comp + 3 + prob.startind]                 # :482
+        absorption = (np.zeros_like(prob.flux) + cont) * voigt_model(prob.wl, _N, _b, _z, wrest, f, gam)   # :483
+        dlambda = np.diff(prob.wl)                               # :485-486
+        dlambda = np.insert(dlambda, 0, dlambda[0])
+        Wtemp = np.sum((1 - (absorption / cont)) * dlambda)      # :488
+        Wtot += Wtemp / (1 + _z)                                 # :489
+    return float(Wtot)
+
+
+def calc_N_reference(prob: Problem, p):
+    """hires_fitter.py:493-505 AS WRITTEN.  The two strides start at the ncomp slot (:499-500) and differ in
+    length by one for every valid parameter vector, so the boolean index raises IndexError -- in the reference
+    exactly as here."""
+    p = np.asarray(p, dtype=float)
+    allN = p[prob.startind::3]                                   # :499
+    allz = p[prob.startind + 1::3]                               # :500
+    okN = (allz < 10)                                            # :502
+    allN = 10 ** allN[okN]                                       # :503
+    return np.log10(np.sum(allN))                                # :505
+
 
 def calc_N_intended(prob: Problem, p) -> float:
     """hires_fitter.py:493-505 with the stride started at the first N slot (the reference starts

@@ -262,8 +262,14 @@ def test_single_line_models_and_equivalent_width(cfgC):
             fit.onecomp_batch([0.0, 1.0, 13.7, 3.0005, 18.0], line=2)
         for p in P:
             for k in range(2):
-                assert abs(fit.calc_w(p, lineid=k) - o.calc_w_intended(prob, p, lineid=k)) < 1e-11
-            assert abs(fit.calc_N(p) - o.calc_N_intended(prob, p)) < 1e-13
+                assert abs(fit.calc_w(p, lineid=k, reference_indexing=False) - o.calc_w_intended(prob, p, lineid=k)) < 1e-11
+                # the reference as written (hires_fitter.py:481-489: all ncompmax slots, sliced from the ncomp slot)
+                want = o.calc_w_reference(prob, p, lineid=k)
+                got = fit.calc_w(p, lineid=k)
+                assert np.isfinite(want) and abs(got - want) <= 1e-11 + 1e-9 * abs(want)
+            assert abs(fit.calc_N(p, reference_indexing=False) - o.calc_N_intended(prob, p)) < 1e-13
+            with pytest.raises(IndexError):                       # :499-503, in the reference as here
+                fit.calc_N(p)
 
 
 def test_full_size_properties_configs_C_and_E(cfgC):
