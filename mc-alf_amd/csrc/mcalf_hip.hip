@@ -1117,16 +1117,24 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         ctx->n_cap = (rmax > sp->velstep) ? (int)std::ceil(kKernelReach * sigma_max) : 0;
     }
     ctx->ncl_cap = std::max(1, ctx->ncompmax * ctx->nlines + ctx->nfill);
-    // lines per barrier: 5 when that saves a barrier at the context's largest line count, else 4
-    ctx->lps = ((ctx->ncl_cap + 4) / 5 < (ctx->ncl_cap + 3) / 4) ? 5 : 4;
+    // Lines per barrier: 5 when that saves a barrier at the context's largest line count and the extra folded
+    // tables cost no tile pixels (LDS), else 4.
+    auto fixed_for = [&](int lps) {
+        return 2 * (size_t)lps * kTabPad + (size_t)ctx->ncl_cap * kRecStride + (2 * (size_t)ctx->n_cap + 8) + kRedDoubles +
+               64 * VT_INODES;
+    };
+    auto ext_for = [&](int lps) {
+        size_t e = kExtMax;
+        while (e > 0 && (fixed_for(lps) + tile_doubles((int)e)) * sizeof(double) > kLdsBudget) e -= 64;
+        return e;
+    };
+    ctx->lps = ((ctx->ncl_cap + 4) / 5 < (ctx->ncl_cap + 3) / 4 && ext_for(5) == ext_for(4)) ? 5 : 4;
     if (const char* e = std::getenv("MCALF_LINES_PER_SYNC")) {
         const int v = std::atoi(e);
-        if (v == 4 || v == 5) ctx->lps = v;
+        if (v == 4 || (v == 5 && ext_for(5) == ext_for(4))) ctx->lps = v;
     }
-    const size_t fixed_doubles = 2 * (size_t)ctx->lps * kTabPad + (size_t)ctx->ncl_cap * kRecStride +
-                                 (2 * (size_t)ctx->n_cap + 8) + kRedDoubles + 64 * VT_INODES;
-    size_t ext = kExtMax;
-    while (ext > 0 && (fixed_doubles + tile_doubles((int)ext)) * sizeof(double) > kLdsBudget) ext -= 64;
+    const size_t fixed_doubles = fixed_for(ctx->lps);
+    size_t ext = ext_for(ctx->lps);
     if (ext < 2 * (size_t)ctx->n_cap + 64)
         return set_err(ctx, MCALF_ERR_RANGE,
                        "LSF half-width %d px (specres_max %.3g km/s at %.3g km/s/px) with %d component-lines does not "
