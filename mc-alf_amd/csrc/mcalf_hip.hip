@@ -313,9 +313,12 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
             fmac_inplace(farNode, mine ? t : 0.0, P);
         }
     }
+    // (tested on 32-bit halves so that each test is one s_bitcmp1_b32 + branch)
+    const unsigned doneLo = (unsigned)done, doneHi = (unsigned)(done >> 32);
 #pragma unroll
     for (int j = 0; j < kPpt; ++j) {
-        if (__builtin_expect((done >> (8 * j)) & 1ULL, 1)) continue;   // whole segment interpolated (wave-uniform, the usual case)
+        const unsigned dbit = ((j < 4 ? doneLo : doneHi) >> (8 * (j & 3))) & 1u;
+        if (__builtin_expect(dbit != 0u, 1)) continue;   // whole segment interpolated (wave-uniform, the usual case)
         const double u = fma(nu[j], A, -B);
         const double x2 = u * u;
         // Every branch leaves (t, P) with contribution t * P, and the running optical depth is updated at ONE
