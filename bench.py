@@ -140,6 +140,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real multi-GPU path) or gloo: a rehearsal of the N>1 control flow on a "
                          "one-GPU box (all ranks share cuda:0, logL shards gathered through host memory)")
+    ap.add_argument("--gather", default="torch", choices=["torch", "inlib"],
+                    help="N>1: torch = torch.distributed.gather of the logL shards (RCCL through torch, depth-2 ring, the "
+                         "default), inlib = the library's own communicator (mcalf_comm_init + mcalf_loglike_gather_device: "
+                         "kernels and one grouped ncclSend/ncclRecv exchange on the launch stream)")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer (PCIe-inclusive) passes")
     ap.add_argument("--no-strong-ref", action="store_true", help="N=1: skip the config-D-on-one-GPU reference")
     ap.add_argument("--inflight", type=int, default=1,
@@ -209,6 +213,7 @@ def main():
             _lib.check(f2._lib.mcalf_reserve(f2._ctx, batch), f2._ctx)
             s2 = torch.cuda.Stream()
             extra.append((f2, s2, torch.empty(batch, dtype=torch.float64, device=dev)))
+    inlib = mdist.InLibGather(fit, batch, dev) if (use_dist and args.gather == "inlib" and not rehearsal) else None
     turn = [0]
     launch = fit._lib.mcalf_loglike_batch_device
     ctx, pP = fit._ctx, dP.data_ptr()
@@ -224,6 +229,10 @@ def main():
                 if rc:
                     _lib.check(rc, f2._ctx)
                 return
+        if inlib is not None:
+            inlib.step(dP, stream)
+            last_out[0] = inlib.local
+            return
         out = dlogL if dlogL is not None else plan.local          # plan.local waits for the slot's old gather
         rc = launch(ctx, pP, batch, out.data_ptr(), st)
         if rc:
@@ -238,7 +247,11 @@ def main():
 
     def fence():
         if use_dist:
-            gathered[0] = plan.finish()                  # every outstanding gather has landed on rank 0
+            if inlib is not None:
+                torch.cuda.synchronize()                 # the exchange is on the launch stream
+                gathered[0] = inlib.all
+            else:
+                gathered[0] = plan.finish()              # every outstanding gather has landed on rank 0
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -388,6 +401,8 @@ def main():
             out["strong_scaling_reference"] = strong_ref
         if use_dist:
             out["rccl_ranks"] = rccl_ranks
+            out["gather"] = ("library (mcalf_loglike_gather_device: grouped ncclSend/ncclRecv on the launch stream)"
+                             if inlib is not None else "torch.distributed.gather, two buffers in flight")
         if args.cpu_seconds > 0 and world == 1:          # the CPU baseline is an N=1 figure (rank 0 only)
             vals, dt, done = cpu_baseline(kw, P_host, args.cpu_seconds)
             k = len(vals)

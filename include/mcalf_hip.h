@@ -48,7 +48,8 @@ enum {
     MCALF_ERR_HIP = -2,       /* a HIP runtime call failed                 */
     MCALF_ERR_NODEVICE = -3,  /* no usable gfx950 device                   */
     MCALF_ERR_RANGE = -4,     /* problem exceeds a build-time capacity     */
-    MCALF_ERR_NOMEM = -5
+    MCALF_ERR_NOMEM = -5,
+    MCALF_ERR_COMM = -6       /* RCCL missing or a collective call failed  */
 };
 
 enum {
@@ -177,6 +178,25 @@ int mcalf_set_prior(mcalf_ctx* ctx, const double* lo, const double* hi, int32_t 
 int mcalf_loglike_cube_batch(mcalf_ctx* ctx, const double* cube, int64_t batch, double* theta, double* logL);
 int mcalf_loglike_cube_batch_device(mcalf_ctx* ctx, const double* dcube, int64_t batch, double* dtheta,
                                     double* dlogL, void* stream);
+
+/* Multi-GPU inside the library (the reference's only parallelism is data parallelism over live
+ * points: PolyChord's MPI workers cli.py:110, jaxns' vmap cli.py:275-280).  One process per GPU, each with its own
+ * context; the context owns an RCCL communicator (xGMI on one node).  Rank 0 obtains a 128-byte id with
+ * mcalf_comm_unique_id and hands it to the other ranks by any means (MPI, torch.distributed, a file); every rank
+ * then calls mcalf_comm_init (collective).  mcalf_loglike_gather_device evaluates the rank's own contiguous block
+ * of live points and enqueues, on the same stream and right behind the kernels, ONE grouped send / receive
+ * exchange that lands every rank's logL block in dlogL_all on `root` (block r at offset r * batch_local; every
+ * rank passes the same batch_local; dlogL_all may be NULL on the other ranks).  Nothing synchronises: the call
+ * returns as soon as the work is enqueued.  Because a live point's arithmetic does not depend on the shard, the
+ * gathered vector equals the single-GPU result bit for bit.  RCCL is loaded at run time by the first of these
+ * calls (MCALF_ERR_COMM if it is absent); single-GPU use never touches it. */
+#define MCALF_COMM_ID_BYTES 128
+int mcalf_comm_unique_id(void* id128);
+int mcalf_comm_init(mcalf_ctx* ctx, const void* id128, int32_t nranks, int32_t rank);
+int mcalf_comm_info(const mcalf_ctx* ctx, int32_t* nranks, int32_t* rank);
+int mcalf_comm_destroy(mcalf_ctx* ctx);
+int mcalf_loglike_gather_device(mcalf_ctx* ctx, const double* dP, int64_t batch_local, double* dlogL_local,
+                                double* dlogL_all, int32_t root, void* stream);
 
 /* Diagnostic: out[i] = H(x[i], y[i]) = Re w(x + i y) evaluated by the device Voigt function
  * (host pointers).  device = -1 for the current device. */

@@ -13,12 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCALF_HIP_LIB") or os.path.join(_HERE, "csrc", "libmcalf_hip.so")
 
 MCALF_OK = 0
-MCALF_ERR_INVALID, MCALF_ERR_HIP, MCALF_ERR_NODEVICE, MCALF_ERR_RANGE, MCALF_ERR_NOMEM = -1, -2, -3, -4, -5
+MCALF_ERR_INVALID, MCALF_ERR_HIP, MCALF_ERR_NODEVICE, MCALF_ERR_RANGE, MCALF_ERR_NOMEM, MCALF_ERR_COMM = -1, -2, -3, -4, -5, -6
+MCALF_COMM_ID_BYTES = 128
 MCALF_CONV_WRAP_NUMPY = 0
 MCALF_CONV_SAME_EDGE_JAX = 1
 
 _ERR_NAMES = {-1: "MCALF_ERR_INVALID", -2: "MCALF_ERR_HIP", -3: "MCALF_ERR_NODEVICE",
-              -4: "MCALF_ERR_RANGE", -5: "MCALF_ERR_NOMEM"}
+              -4: "MCALF_ERR_RANGE", -5: "MCALF_ERR_NOMEM", -6: "MCALF_ERR_COMM"}
 
 
 class mcalf_line(C.Structure):
@@ -89,6 +90,11 @@ SYMBOLS = {
     "mcalf_set_prior": (C.c_int, [_CTX, _PD, _PD, C.c_int32]),
     "mcalf_loglike_cube_batch": (C.c_int, [_CTX, _PD, C.c_int64, _PD, _PD]),
     "mcalf_loglike_cube_batch_device": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mcalf_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mcalf_comm_init": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32]),
+    "mcalf_comm_info": (C.c_int, [_CTX, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mcalf_comm_destroy": (C.c_int, [_CTX]),
+    "mcalf_loglike_gather_device": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "mcalf_voigt_hjerting": (C.c_int, [_PD, _PD, C.c_int64, _PD, C.c_int32]),
     "mcalf_voigt_hjerting_nodes": (C.c_int, [_PD, _PD, C.c_int64, _PD, C.c_int32]),
 }

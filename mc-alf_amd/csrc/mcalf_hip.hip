@@ -15,6 +15,8 @@
 // The C ABI is declared in include/mcalf_hip.h.  There is no CPU fallback: every entry point
 // fails with MCALF_ERR_NODEVICE when no gfx950 device is present.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the library is resolved at run time (mcalf_comm_*), never linked
 
 #include <cmath>
 #include <cstdarg>
@@ -970,6 +972,9 @@ struct mcalf_ctx {
     unsigned int* d_queue = nullptr;    // [kMaxChunks] work-item queues of the persistent kernel
     hipStream_t aux[kMaxChunks - 1] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxChunks - 1] = {};
+    // multi-GPU: the communicator of mcalf_comm_init (one process per GPU, RCCL over xGMI)
+    ncclComm_t comm = nullptr;
+    int comm_ranks = 0, comm_rank = -1;
     // page-locked staging of the host-pointer entries: parameter rows in, scalars out
     double* h_stage = nullptr;
     size_t cap_stage = 0;
@@ -1037,9 +1042,12 @@ extern "C" const char* mcalf_last_error(const mcalf_ctx* ctx) {
     return ctx ? ctx->err.c_str() : g_last_error.c_str();
 }
 
+static void comm_release(mcalf_ctx* ctx);
+
 extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    comm_release(ctx);
     void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_err, ctx->d_tabs, ctx->d_lines, ctx->d_wtab, ctx->d_segok,
                     ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds, ctx->d_prior, ctx->d_recs, ctx->d_taps, ctx->d_hdr,
                     ctx->d_queue};
@@ -1642,6 +1650,142 @@ extern "C" int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batc
         return set_err(ctx, MCALF_ERR_INVALID, "onecomp: `which` must be 0 (all lines), 1 (filler) or 2+k with k < %d",
                        ctx->nlines);
     return run_host(ctx, kModeOneComp, Q, batch, 5, 0, which, nullptr, flux);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Multi-GPU inside the library: one process per GPU, each with its own context; the context
+// owns an RCCL communicator and the per-sample logL shards travel to the root rank as ONE grouped send/receive
+// exchange (what ncclGather is) enqueued on the launch stream right behind the kernels -- no host round trip, no
+// Python in the step.  RCCL is resolved with dlopen at the first mcalf_comm_* call (torch's bundled librccl when
+// torch is in the process, the ROCm one otherwise), so the single-GPU path has no dependency on it.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+RcclApi g_rccl;
+
+int rccl_load(mcalf_ctx* ctx) {
+    if (g_rccl.ok) return MCALF_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names)                           // a copy already in the process (torch's) wins
+        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+    for (int i = 0; !h && i < 2; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return set_err(ctx, MCALF_ERR_COMM, "librccl.so not found: %s", dlerror());
+    g_rccl.handle = h;
+#define MCALF_SYM(field, sym)                                                                     \
+    if (!(g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, sym))))                \
+        return set_err(ctx, MCALF_ERR_COMM, "librccl.so lacks %s", sym);
+    MCALF_SYM(GetUniqueId, "ncclGetUniqueId")
+    MCALF_SYM(CommInitRank, "ncclCommInitRank")
+    MCALF_SYM(CommDestroy, "ncclCommDestroy")
+    MCALF_SYM(Send, "ncclSend")
+    MCALF_SYM(Recv, "ncclRecv")
+    MCALF_SYM(GroupStart, "ncclGroupStart")
+    MCALF_SYM(GroupEnd, "ncclGroupEnd")
+    MCALF_SYM(GetErrorString, "ncclGetErrorString")
+#undef MCALF_SYM
+    g_rccl.ok = true;
+    return MCALF_OK;
+}
+}  // namespace
+
+#define RCCL_TRY(ctx, expr)                                                                                   \
+    do {                                                                                                      \
+        ncclResult_t r_ = (expr);                                                                             \
+        if (r_ != ncclSuccess)                                                                                \
+            return set_err(ctx, MCALF_ERR_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));           \
+    } while (0)
+
+static void comm_release(mcalf_ctx* ctx) {
+    if (ctx->comm && g_rccl.ok) (void)g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_ranks = 0;
+    ctx->comm_rank = -1;
+}
+
+extern "C" int mcalf_comm_unique_id(void* id128) {
+    if (!id128) return set_err(nullptr, MCALF_ERR_INVALID, "id is NULL");
+    int rc = rccl_load(nullptr);
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == MCALF_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    RCCL_TRY(nullptr, g_rccl.GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof id);
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_comm_init(mcalf_ctx* ctx, const void* id128, int32_t nranks, int32_t rank) {
+    if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks)
+        return set_err(ctx, MCALF_ERR_INVALID, "mcalf_comm_init: bad arguments (nranks %d, rank %d)", nranks, rank);
+    int rc = rccl_load(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    comm_release(ctx);
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    RCCL_TRY(ctx, g_rccl.CommInitRank(&ctx->comm, nranks, id, rank));      // collective over all ranks
+    ctx->comm_ranks = nranks;
+    ctx->comm_rank = rank;
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_comm_info(const mcalf_ctx* ctx, int32_t* nranks, int32_t* rank) {
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    if (nranks) *nranks = ctx->comm_ranks;
+    if (rank) *rank = ctx->comm_rank;
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_comm_destroy(mcalf_ctx* ctx) {
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    comm_release(ctx);
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_loglike_gather_device(mcalf_ctx* ctx, const double* dP, int64_t batch_local, double* dlogL_local,
+                                           double* dlogL_all, int32_t root, void* stream) {
+    if (!ctx || batch_local < 0 || (batch_local > 0 && (!dP || !dlogL_local)))
+        return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    if (!ctx->comm) return set_err(ctx, MCALF_ERR_INVALID, "mcalf_comm_init has not been called");
+    if (root < 0 || root >= ctx->comm_ranks) return set_err(ctx, MCALF_ERR_INVALID, "root %d out of range", root);
+    const bool is_root = ctx->comm_rank == root;
+    if (is_root && batch_local > 0 && !dlogL_all) return set_err(ctx, MCALF_ERR_INVALID, "root needs dlogL_all");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch(ctx, kModeLogL, dP, batch_local, 0, 0, dlogL_local, nullptr, st);
+    if (rc) return rc;
+    if (batch_local == 0) return MCALF_OK;
+    const size_t n = (size_t)batch_local;
+    if (is_root) {
+        HIP_TRY(ctx, hipMemcpyAsync(dlogL_all + (size_t)root * n, dlogL_local, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (ctx->comm_ranks > 1) {
+            RCCL_TRY(ctx, g_rccl.GroupStart());
+            for (int r = 0; r < ctx->comm_ranks; ++r) {
+                if (r == root) continue;
+                ncclResult_t e = g_rccl.Recv(dlogL_all + (size_t)r * n, n, ncclFloat64, r, ctx->comm, st);
+                if (e != ncclSuccess) {
+                    (void)g_rccl.GroupEnd();
+                    return set_err(ctx, MCALF_ERR_COMM, "ncclRecv from rank %d failed: %s", r, g_rccl.GetErrorString(e));
+                }
+            }
+            RCCL_TRY(ctx, g_rccl.GroupEnd());
+        }
+    } else {
+        RCCL_TRY(ctx, g_rccl.Send(dlogL_local, n, ncclFloat64, root, ctx->comm, st));
+    }
+    return MCALF_OK;
 }
 
 extern "C" int mcalf_set_prior(mcalf_ctx* ctx, const double* lo, const double* hi, int32_t int_ncomp) {

@@ -11,10 +11,13 @@ data-parallelism is PolyChord's MPI master/worker (cli.py:110) or jaxns' vmap (c
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+from . import _lib
 
 
 def shard_bounds(batch: int, world: int, rank: int) -> Tuple[int, int]:
@@ -119,3 +122,40 @@ def sharded_loglike(evaluate: Callable[[int, int, torch.Tensor], None], batch: i
     g = LogLGather(batch, device, dst=dst, group=group)
     evaluate(g.lo, g.hi, g.local)
     return g.gather()
+
+
+class InLibGather:
+    """The same exchange done INSIDE the library: the context owns an RCCL communicator and
+    `mcalf_loglike_gather_device` enqueues kernels + one grouped send/receive on the launch stream -- no Python
+    and no host round trip in the step.  torch.distributed (any backend) is used once, to hand rank 0's 128-byte
+    RCCL id to the other ranks; without an initialised process group this is a one-rank communicator.
+
+    Every rank evaluates `batch_local` rows (equal shards); `self.all` on `root` holds [world * batch_local]."""
+
+    def __init__(self, fit, batch_local: int, device, root: int = 0, group=None):
+        self.fit, self.root, self.n = fit, root, int(batch_local)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        ident = [None]
+        if self.rank == root:
+            buf = C.create_string_buffer(_lib.MCALF_COMM_ID_BYTES)
+            _lib.check(fit._lib.mcalf_comm_unique_id(buf))
+            ident[0] = buf.raw
+        if self.world > 1:
+            dist.broadcast_object_list(ident, src=root, group=group)
+        self._id = C.create_string_buffer(ident[0], _lib.MCALF_COMM_ID_BYTES)
+        _lib.check(fit._lib.mcalf_comm_init(fit._ctx, self._id, self.world, self.rank), fit._ctx)
+        self.local = torch.empty(self.n, dtype=torch.float64, device=device)
+        self.all = torch.empty(self.n * self.world, dtype=torch.float64, device=device) if self.rank == root else None
+
+    def step(self, dP: torch.Tensor, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """Evaluate this rank's rows `dP` [batch_local][ndim] and enqueue the gather (asynchronous)."""
+        st = stream if stream is not None else torch.cuda.current_stream()
+        rc = self.fit._lib.mcalf_loglike_gather_device(
+            self.fit._ctx, dP.data_ptr(), self.n, self.local.data_ptr(),
+            self.all.data_ptr() if self.all is not None else None, self.root, C.c_void_p(st.cuda_stream))
+        if rc:
+            _lib.check(rc, self.fit._ctx)
+
+    def close(self):
+        _lib.check(self.fit._lib.mcalf_comm_destroy(self.fit._ctx), self.fit._ctx)

@@ -130,3 +130,56 @@ def test_jax_kernel_grid_comes_from_the_second_specres_entry():
         got = fit.loglike_batch(P)
     want = np.array([o.jax_loglike_f64(prob, p) for p in P])
     assert np.abs(got - want).max() < LOGL_ATOL
+
+
+def test_in_library_gather_on_a_one_rank_communicator():
+    """mcalf_comm_* + mcalf_loglike_gather_device: RCCL is loaded at run time, the context owns the
+    communicator, the gather lands the rank's block in the root's vector.  One rank here (a GPU box has one GPU);
+    the N > 1 exchange is the same grouped ncclSend / ncclRecv with more peers."""
+    import ctypes as C
+    import torch
+    from mcalf_amd import _lib
+    from mcalf_amd import dist as mdist
+    kw, _, seed = workloads.config("C", oracle_synth)
+    P = workloads.draw_P(kw, 700, np.random.default_rng(seed + 41))
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        want = fit.loglike_batch(P)
+        n, r = C.c_int32(-1), C.c_int32(-1)
+        _lib.check(fit._lib.mcalf_comm_info(fit._ctx, C.byref(n), C.byref(r)), fit._ctx)
+        assert (n.value, r.value) == (0, -1)                      # no communicator yet
+        dP = torch.from_numpy(P).cuda()
+        with pytest.raises(RuntimeError, match="mcalf_comm_init"):
+            _lib.check(fit._lib.mcalf_loglike_gather_device(fit._ctx, dP.data_ptr(), 700, dP.data_ptr(), dP.data_ptr(), 0, None),
+                       fit._ctx)
+        g = mdist.InLibGather(fit, 700, "cuda")
+        _lib.check(fit._lib.mcalf_comm_info(fit._ctx, C.byref(n), C.byref(r)), fit._ctx)
+        assert (n.value, r.value) == (1, 0)
+        for _ in range(3):
+            g.step(dP)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.local.cpu().numpy(), want) and np.array_equal(g.all.cpu().numpy(), want)
+        g.close()
+        _lib.check(fit._lib.mcalf_comm_info(fit._ctx, C.byref(n), C.byref(r)), fit._ctx)
+        assert n.value == 0
+
+
+def test_two_rank_job_through_the_product_path_on_one_gpu():
+    """bench.py --gpus 2 --backend gloo: two processes, each with its own context on the one GPU of the box, the
+    real kernels, the row sharding of mcalf_amd.dist and a (gloo) gather of the logL shards to rank 0 -- the N > 1
+    control flow of the driver's multi-GPU runs with everything but the RCCL transport."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "D",
+           "--batch", "2048", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["rccl_ranks"] == 2
+    assert out["config"]["batch_per_gpu"] == 1024 and out["config"]["global_batch"] == 2048
+    assert out["gather_check"] == {"rows": 2048, "own_block_equal": True, "all_finite": True}
+    assert out["parity"]["max_abs_dlogL_vs_oracle"] < LOGL_ATOL
