@@ -762,9 +762,10 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
                     const int p = tid + j * kBlock;        // pixel index; tile layout [n halo | npix body | n halo]
                     if (p < a.npix) {
                         sF[tile_pos(p + n)] = fl[jj];
-                        // periodic copies (astropy boundary='wrap'); the JAX path pads with zeros instead (:674)
-                        if (p < n) sF[tile_pos(p + n + a.npix)] = kZeroPad ? 0.0 : fl[jj];
-                        if (p >= a.npix - n) sF[tile_pos(p + n - a.npix)] = kZeroPad ? 0.0 : fl[jj];
+                        // periodic copies (astropy boundary='wrap'); the JAX path pads with zeros instead (:674).
+                        // Only the first / last pixel groups can hold halo pixels: a scalar test skips the rest.
+                        if (j * kBlock < n && p < n) sF[tile_pos(p + n + a.npix)] = kZeroPad ? 0.0 : fl[jj];
+                        if ((j + 1) * kBlock > a.npix - n && p >= a.npix - n) sF[tile_pos(p + n - a.npix)] = kZeroPad ? 0.0 : fl[jj];
                     }
                 } else {
                     const int pos = tid + j * kBlock - shift;
@@ -813,6 +814,23 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
                 wp += 8;
             }
             const double ibot = 1.0 / bot;
+            // The plain log-likelihood (no model output, no asymmetric veto, numpy boundary) gets its own loop: in
+            // the general one below every pixel drags the mode / veto / output tests along as selects and reloads
+            // of spilled scalars (~30 vector instructions per pixel against ~12 here).  Same arithmetic, same order.
+            const bool plainLogL = !kZeroPad && a.mode == kModeLogL && !a.asymm && a.model == nullptr;
+            if (plainLogL) {
+                if (!bad) {                                      // (bad: every term is NaN and is dropped)
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        double mval = top[m] * ibot;
+                        mval *= cont;                                                          // :447
+                        const double d = ob[m] - mval;
+                        double term = is2[m] * (d * d);
+                        term = (term - lg[m]) + a.log2pi;                                      // :294
+                        acc += (base + m < tlen && !isnan(term)) ? term : 0.0;                 // np.nansum
+                    }
+                }
+            } else
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int i = base + m;
