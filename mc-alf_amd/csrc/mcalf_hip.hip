@@ -702,13 +702,26 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
                 double Tn[VT_NY];
 #pragma unroll
                 for (int nn = 0; nn < VT_NY; ++nn) Tn[nn] = sT[nn * VT_NTOT + tid];
+                // No test per line: past the last record the last one is folded again into a slot nobody reads.
+                // The group's Horner chains are written step by step ACROSS the lines, so that they issue
+                // interleaved (the fold sits on every wave's path to the barrier; chain after chain it is bound by
+                // the latency of 6 dependent FMAs per line).
+                double fy[kLinesPerSync], fs[kLinesPerSync], fc[kLinesPerSync];
 #pragma unroll
                 for (int l = 0; l < kLinesPerSync; ++l) {
-                    // no test per line: past the last record the last one is folded again into a slot nobody
-                    // reads, which keeps the group's folds independent chains the scheduler can interleave
                     const double* rec = sRec + min(cl0 + l, ncl_run - 1) * kRecStride;
-                    tabs[l * kTabPad + coefPos] = fold_coef(Tn, rec[3], coreCoef ? rec[4] : rec[5]);
+                    fy[l] = rec[3];
+                    fs[l] = coreCoef ? rec[4] : rec[5];
+                    fc[l] = Tn[VT_NY - 1];
                 }
+#pragma unroll
+                for (int nn = VT_NY - 2; nn >= 0; --nn) {
+#pragma unroll
+                    for (int l = 0; l < kLinesPerSync; ++l) fc[l] = fma(fc[l], fy[l], Tn[nn]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int l = 0; l < kLinesPerSync; ++l) tabs[l * kTabPad + coefPos] = fc[l] * fs[l];   // = fold_coef()
             }
             __syncthreads();
             buf ^= 1;
@@ -735,6 +748,12 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             for (int k = 0; k < VT_INODES; ++k) wrow[k] = sWt[k * 64 + (tid & 63)];
         }
         const int extTight = tlen + 2 * n;
+        // Tile positions of this thread's pixels: a step of kBlock pixels (a multiple of 8) moves an element by
+        // kBlock / 8 slots inside its plane, so ONE position per destination (body, low halo copy, high halo copy)
+        // serves all eight pixels as base + 64 j.
+        const int posBody = tile_pos(selfHalo ? tid + n : tid - shift);
+        const int posLow = tile_pos(tid + n + a.npix), posHigh = tile_pos(tid + n - a.npix);   // (self-halo copies)
+        static_assert(kBlock % 8 == 0, "tile_pos(i + kBlock) == tile_pos(i) + kBlock / 8");
         // Two pixels per round: their interpolation sums and exponentials are independent chains the scheduler
         // interleaves (one pixel at a time the phase is bound by the latency of a single ~35-instruction chain).
         // The fences keep it at two: without them the compiler issues the node sums of all eight segments at
@@ -761,15 +780,15 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
                 if (selfHalo) {
                     const int p = tid + j * kBlock;        // pixel index; tile layout [n halo | npix body | n halo]
                     if (p < a.npix) {
-                        sF[tile_pos(p + n)] = fl[jj];
+                        sF[posBody + (kBlock / 8) * j] = fl[jj];
                         // periodic copies (astropy boundary='wrap'); the JAX path pads with zeros instead (:674).
                         // Only the first / last pixel groups can hold halo pixels: a scalar test skips the rest.
-                        if (j * kBlock < n && p < n) sF[tile_pos(p + n + a.npix)] = kZeroPad ? 0.0 : fl[jj];
-                        if ((j + 1) * kBlock > a.npix - n && p >= a.npix - n) sF[tile_pos(p + n - a.npix)] = kZeroPad ? 0.0 : fl[jj];
+                        if (j * kBlock < n && p < n) sF[posLow + (kBlock / 8) * j] = kZeroPad ? 0.0 : fl[jj];
+                        if ((j + 1) * kBlock > a.npix - n && p >= a.npix - n) sF[posHigh + (kBlock / 8) * j] = kZeroPad ? 0.0 : fl[jj];
                     }
                 } else {
                     const int pos = tid + j * kBlock - shift;
-                    if (pos >= 0 && pos < extTight) sF[tile_pos(pos)] = fl[jj];
+                    if (pos >= 0 && pos < extTight) sF[posBody + (kBlock / 8) * j] = fl[jj];
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
