@@ -35,9 +35,9 @@ rep("template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync>\n__global__ __l
 rep("                                          double& farNode, unsigned long long segOk) {\n    const double A = rec[0], B = rec[1], x2c = rec[2];",
     "                                          double& farNode, unsigned long long segOk, unsigned long long& accNode, unsigned long long& accDirect) {\n"
     "    const unsigned long long c0 = __builtin_amdgcn_s_memtime();\n    const double A = rec[0], B = rec[1], x2c = rec[2];")
-rep("#pragma unroll\n    for (int j = 0; j < kPpt; ++j) {\n        if (__builtin_expect((done >> (8 * j)) & 1ULL, 1)) continue;",
-    "    const unsigned long long c1 = __builtin_amdgcn_s_memtime();\n    accNode += c1 - c0;\n#pragma unroll\n"
-    "    for (int j = 0; j < kPpt; ++j) {\n        if (__builtin_expect((done >> (8 * j)) & 1ULL, 1)) continue;")
+rep("    const unsigned doneLo = (unsigned)done, doneHi = (unsigned)(done >> 32);",
+    "    const unsigned long long c1 = __builtin_amdgcn_s_memtime();\n    accNode += c1 - c0;\n"
+    "    const unsigned doneLo = (unsigned)done, doneHi = (unsigned)(done >> 32);")
 rep("        fmac_inplace(tau[j], t, P);\n    }\n}", "        fmac_inplace(tau[j], t, P);\n    }\n    accDirect += __builtin_amdgcn_s_memtime() - c1;\n}")
 rep("eval_line(tabs + l * kTabPad, sRec + (cl0 + l) * kRecStride, nu, tau, nuNode, farNode, segOk);",
     "eval_line(tabs + l * kTabPad, sRec + (cl0 + l) * kRecStride, nu, tau, nuNode, farNode, segOk, accNode, accDirect);")
