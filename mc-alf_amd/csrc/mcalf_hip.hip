@@ -285,7 +285,9 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
         const double un = fma(nuNode, A, -B);
         // issued ahead of the scalar mask chain below, which then runs in the shadow of the reciprocal
         const double x2n = un * un;
-        const double t = fast_rcp(fmax(x2n, kX2Mid));         // lanes outside `mine` only need to stay finite
+        // lanes outside `mine` only need to stay finite (mine lanes have x2n >= uthr^2 >= 36; 4.0 is an inline
+        // constant, 36.0 costs two scalar moves per line)
+        const double t = fast_rcp(fmax(x2n, 4.0));
         unsigned long long mp = __builtin_amdgcn_ballot_w64(un >= uthr);
         unsigned long long mn = __builtin_amdgcn_ballot_w64(un <= -uthr);
         // u is monotonic along a segment (segOk excludes the wrapped ones), so its two END nodes -- lanes 8j
@@ -297,10 +299,12 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
         if ((threadIdx.x & 63) == 0) { atomicAdd(&g_dbg[0], (unsigned long long)__popcll(done)); atomicAdd(&g_dbg[1], 8ULL); atomicAdd(&g_dbg[2], (unsigned long long)__popcll(segOk)); }
 #endif
         if (done != 0) {                                      // wave-uniform
-            const unsigned long long lanes = (done << 8) - done;     // byte j -> 0xFF: one bit per lane
+            // byte j -> 0xFF: one bit per lane.  On 32-bit halves (no carry can cross: 0x01010101 * 0xFF = 0xFFFFFFFF),
+            // which is two scalar multiplies instead of a 64-bit one.
+            const unsigned long long lanes = ((unsigned long long)((unsigned)(done >> 32) * 0xFFu) << 32) | ((unsigned)done * 0xFFu);
             const bool mine = __builtin_amdgcn_inverse_ballot_w64(lanes);   // the scalar mask IS the lane predicate
             double P;
-            if (uthr >= VT_XFAR || x2n >= kX2Far) {               // (first test is uniform: strong lines only ever use zone F)
+            if (!mine || x2n >= kX2Far) {                         // (lanes of directly evaluated segments never need a wing zone)
                 P = cF[VT_FDEG];
 #pragma unroll
                 for (int k = VT_FDEG - 1; k >= 0; --k) P = fma(P, t, cF[k]);
@@ -341,10 +345,11 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
         } else {                                      // |u| < 8: core table (per-lane LDS gather).  It is valid up to 8, so the
                                                       // pixels between x_c and 8 come here too instead of splitting the wave over
                                                       // a third path (zone 1 serves the interpolation nodes only)
-            const double x = fabs(u);
-            int jx = (int)(x * 4.0);
-            jx = min(max(jx, 0), VT_NINT - 1);
-            const double sv = fma(x, 8.0, -(double)(2 * jx + 1));
+            // |u| < 8 here (NaN converts to 0), so the interval index needs no clamp; s = 8|u| - (2j+1) from 4|u|
+            // with the inline constant 2.0 (same value bit for bit, 8.0 costs two scalar moves per segment)
+            const double x4 = fabs(u) * 4.0;
+            const int jx = (int)x4;
+            const double sv = fma(x4, 2.0, -(double)(2 * jx + 1));
             const double* cc = tab + jx * VT_CSTRIDE;
             P = cc[VT_CDEG];
 #pragma unroll
@@ -725,11 +730,12 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             }
             __syncthreads();
             buf ^= 1;
-#pragma unroll 1                 // one copy of the (large) per-line body: keeps the loop inside the instruction cache
-            for (int l = 0; l < kLinesPerSync; ++l) {
-                if (cl0 + l < ncl_run)
-                    eval_line(tabs + l * kTabPad, sRec + (cl0 + l) * kRecStride, nu, tau, nuNode, farNode, segOk);
-            }
+            // one copy of the (large) per-line body: keeps the loop inside the instruction cache
+            const int lmax = __builtin_amdgcn_readfirstlane(min(kLinesPerSync, ncl_run - cl0));   // (kept scalar)
+            const double* grec = sRec + cl0 * kRecStride;
+#pragma unroll 1
+            for (int l = 0; l < lmax; ++l)
+                eval_line(tabs + l * kTabPad, grec + l * kRecStride, nu, tau, nuNode, farNode, segOk);
         }
         if (hd.ngeneral > 0 && ncl_run > 0) eval_general_lines(sRec, ncl, nu, tau);
         MCALF_STAMP(3);
