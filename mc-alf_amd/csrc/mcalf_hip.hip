@@ -45,6 +45,7 @@ constexpr int kZFLds = VT_ZF_OFF + 2;
 // config E, 16 lines, +1.3 % with 5).
 constexpr int kLinesPerSyncMax = 5;
 static_assert(kBlock == 64 * VT_INODES, "one interpolation weight per thread");
+static_assert(kPpt == 8, "the skip tests of eval_line treat the eight segments of a wave as two halves");
 static_assert(VT_NTOT <= 512 && (kZ0Lds % 2) == 0 && (kZFLds % 2) == 0 && (kTabPad % 2) == 0, "LDS table layout");
 constexpr int kRedDoubles = 3 * kWaves + 2;   // per-wave partials (sum, count, scratch) + the next work-item index
 constexpr int kTileSlack = 16;           // zero-filled entries past the halo (sliding-window over-read)
@@ -319,12 +320,17 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
             fmac_inplace(farNode, mine ? t : 0.0, P);
         }
     }
-    // (tested on 32-bit halves so that each test is one s_bitcmp1_b32 + branch)
+    // Tested on 32-bit halves (one s_bitcmp1_b32 + branch per segment), four segments at a time first: a line's
+    // core covers one or two ADJACENT segments of a wave, so one half of the eight is usually interpolated throughout.
     const unsigned doneLo = (unsigned)done, doneHi = (unsigned)(done >> 32);
 #pragma unroll
-    for (int j = 0; j < kPpt; ++j) {
-        const unsigned dbit = ((j < 4 ? doneLo : doneHi) >> (8 * (j & 3))) & 1u;
-        if (__builtin_expect(dbit != 0u, 1)) continue;   // whole segment interpolated (wave-uniform, the usual case)
+    for (int h = 0; h < kPpt / 4; ++h) {
+    const unsigned dh = h ? doneHi : doneLo;
+    if (dh == 0x01010101u) continue;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * h + jj;
+        if (__builtin_expect(((dh >> (8 * jj)) & 1u) != 0u, 1)) continue;   // whole segment interpolated (wave-uniform, the usual case)
         const double u = fma(nu[j], A, -B);
         const double x2 = u * u;
         // Every branch leaves (t, P) with contribution t * P, and the running optical depth is updated at ONE
@@ -357,6 +363,7 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
             t = 1.0;                                  // tau += 1 * P rounds exactly like tau += P
         }
         fmac_inplace(tau[j], t, P);
+    }
     }
 }
 
@@ -658,7 +665,6 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         const double cont = hd.cont, bot = hd.bot;
         const int ncl = hd.ncl, n = hd.n;
         const bool bad = hd.bad != 0;
-        const int ntap8 = (2 * n + 1 + 7) & ~7;
 #pragma unroll
         for (int i = 0; i < kRecRegs; ++i)
             if (tid + i * kBlock < recTotal) sRec[tid + i * kBlock] = L.rreg[i];
@@ -827,7 +833,8 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
 #pragma unroll
             for (int m = 0; m < 8; ++m) { win[m] = fp[m * kPlaneStride]; top[m] = 0.0; }
             const double* wp = sW;
-            for (int q0 = 0; q0 < ntap8; q0 += 8) {
+            const int ntaps = 2 * n + 1;
+            for (int q0 = 0; q0 + 8 <= ntaps; q0 += 8) {   // whole groups of eight taps
                 ++fp;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -837,6 +844,18 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
                     win[r] = fp[r * kPlaneStride];         // element base + q0 + r + 8
                 }
                 wp += 8;
+            }
+            {                                              // the last 1..7 taps (2n+1 is odd): no zero-weight padding taps
+                const int rem = ntaps & 7;                 // wave-uniform
+                ++fp;
+#pragma unroll
+                for (int r = 0; r < 7; ++r) {
+                    if (r >= rem) break;
+                    const double wgt = wp[r];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) top[m] = fma(win[(m + r) & 7], wgt, top[m]);
+                    win[r] = fp[r * kPlaneStride];
+                }
             }
             const double ibot = 1.0 / bot;
             // The plain log-likelihood (no model output, no asymmetric veto, numpy boundary) gets its own loop: in

@@ -38,7 +38,7 @@ rep("                                          double& farNode, unsigned long lo
 rep("    const unsigned doneLo = (unsigned)done, doneHi = (unsigned)(done >> 32);",
     "    const unsigned long long c1 = __builtin_amdgcn_s_memtime();\n    accNode += c1 - c0;\n"
     "    const unsigned doneLo = (unsigned)done, doneHi = (unsigned)(done >> 32);")
-rep("        fmac_inplace(tau[j], t, P);\n    }\n}", "        fmac_inplace(tau[j], t, P);\n    }\n    accDirect += __builtin_amdgcn_s_memtime() - c1;\n}")
+rep("        fmac_inplace(tau[j], t, P);\n    }\n    }\n}", "        fmac_inplace(tau[j], t, P);\n    }\n    }\n    accDirect += __builtin_amdgcn_s_memtime() - c1;\n}")
 rep("eval_line(tabs + l * kTabPad, grec + l * kRecStride, nu, tau, nuNode, farNode, segOk);",
     "eval_line(tabs + l * kTabPad, grec + l * kRecStride, nu, tau, nuNode, farNode, segOk, accNode, accDirect);")
 rep("            double* tabs = sTab + buf * (kLinesPerSync * kTabPad);\n            if (hasCoef) {",
