@@ -37,16 +37,19 @@ constexpr int kPpt = 8;                 // pixels per thread: (tile + halo) <= k
 constexpr int kExtMax = kBlock * kPpt;  // 4096 pixels = 32 KiB of LDS
 constexpr int kWaves = kBlock / 64;
 constexpr int kRecStride = 8;           // doubles per (component,line) record in LDS
-constexpr int kTabPad = VT_NTOT + 3;    // folded table in LDS: zone0 / zoneF shifted to stay 16-B aligned
+constexpr int kTabPad = VT_NTOT + 7;    // folded table in LDS: zone0 / zoneF shifted to stay 16-B aligned, then uthr, A, B
 constexpr int kZ0Lds = VT_Z0_OFF + 1;
 constexpr int kZFLds = VT_ZF_OFF + 2;
+constexpr int kLineLds = kZFLds + VT_FDEG + 1;   // [uthr, A, B] of the line, right behind its zone-F coefficients: the
+                                                 // node pass reads all ten doubles off ONE base address (5 x ds_read_b128)
+static_assert(kLineLds + 3 <= kTabPad && (kLineLds % 2) == 1, "line constants pair up with the last zone-F coefficient");
 // Lines folded per workgroup barrier of the component loop: 4 or 5, chosen per context (whichever needs fewer
 // barriers for the context's largest line count; measured on MI355X: config C, 20-24 lines, -0.8 % with 5;
 // config E, 16 lines, +1.3 % with 5).
 constexpr int kLinesPerSyncMax = 5;
 static_assert(kBlock == 64 * VT_INODES, "one interpolation weight per thread");
 static_assert(kPpt == 8, "the skip tests of eval_line treat the eight segments of a wave as two halves");
-static_assert(VT_NTOT <= 512 && (kZ0Lds % 2) == 0 && (kZFLds % 2) == 0 && (kTabPad % 2) == 0, "LDS table layout");
+static_assert(VT_NTOT <= kBlock - 64 && (kZ0Lds % 2) == 0 && (kZFLds % 2) == 0 && (kTabPad % 2) == 0, "LDS table layout");
 constexpr int kRedDoubles = 3 * kWaves + 2;   // per-wave partials (sum, count, scratch) + the next work-item index
 constexpr int kTileSlack = 16;           // zero-filled entries past the halo (sliding-window over-read)
 constexpr size_t kLdsBudget = 78 * 1024;   // two workgroups per CU (160 KiB); needs the MaxDynamicSharedMemorySize attribute
@@ -267,11 +270,11 @@ __device__ __forceinline__ void add_inplace(double& acc, double a) {
 }
 
 // tau[j] += K H(u_j, y) for the thread's kPpt pixels and one (component,line); `tab` is the line's
-// folded table in LDS, `rec` its record.
-__device__ __forceinline__ void eval_line(const double* __restrict__ tab, const double* __restrict__ rec,
+// folded table in LDS (coefficients, then the line's threshold and the (A, B) of u = nu A - B).
+__device__ __forceinline__ void eval_line(const double* __restrict__ tab,
                                           const double (&nu)[kPpt], double (&tau)[kPpt], double nuNode,
                                           double& farNode, unsigned long long segOk) {
-    const double A = rec[0], B = rec[1], x2c = rec[2];
+    const double A = tab[kLineLds + 1], B = tab[kLineLds + 2];
     double cF[VT_FDEG + 1];
 #pragma unroll
     for (int k = 0; k <= VT_FDEG; ++k) cF[k] = tab[kZFLds + k];
@@ -282,7 +285,7 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
     // segment j was handled that way.
     unsigned long long done = 0;
     if (kFarInterp) {
-        const double uthr = rec[7];
+        const double uthr = tab[kLineLds];
         const double un = fma(nuNode, A, -B);
         // issued ahead of the scalar mask chain below, which then runs in the shadow of the reciprocal
         const double x2n = un * un;
@@ -295,7 +298,7 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab, const 
         // and 8j+7, the segment's first and last pixel -- decide for all eight.
         mp &= mp >> 7;                                        // bit 8j = first and last node
         mn &= mn >> 7;
-        done = uniform64((mp | mn) & segOk & 0x0101010101010101ULL);
+        done = uniform64((mp | mn) & segOk);                 // (segOk carries bits 8j only, so `done` does too)
 #ifdef MCALF_COUNT_INTERP
         if ((threadIdx.x & 63) == 0) { atomicAdd(&g_dbg[0], (unsigned long long)__popcll(done)); atomicAdd(&g_dbg[1], 8ULL); atomicAdd(&g_dbg[2], (unsigned long long)__popcll(segOk)); }
 #endif
@@ -733,15 +736,20 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
                 }
 #pragma unroll
                 for (int l = 0; l < kLinesPerSync; ++l) tabs[l * kTabPad + coefPos] = fc[l] * fs[l];   // = fold_coef()
+            } else if (tid >= kBlock - 64 && tid < kBlock - 64 + 3) {
+                // the last wave folds nothing: three of its lanes copy each line's [uthr, A, B] behind its coefficients
+                const int which = tid - (kBlock - 64);                                 // 0: uthr, 1: A, 2: B
+                const int src = (which == 0) ? 7 : which - 1;
+#pragma unroll
+                for (int l = 0; l < kLinesPerSync; ++l)
+                    tabs[l * kTabPad + kLineLds + which] = sRec[min(cl0 + l, ncl_run - 1) * kRecStride + src];
             }
             __syncthreads();
             buf ^= 1;
             // one copy of the (large) per-line body: keeps the loop inside the instruction cache
             const int lmax = __builtin_amdgcn_readfirstlane(min(kLinesPerSync, ncl_run - cl0));   // (kept scalar)
-            const double* grec = sRec + cl0 * kRecStride;
 #pragma unroll 1
-            for (int l = 0; l < lmax; ++l)
-                eval_line(tabs + l * kTabPad, grec + l * kRecStride, nu, tau, nuNode, farNode, segOk);
+            for (int l = 0; l < lmax; ++l) eval_line(tabs + l * kTabPad, nu, tau, nuNode, farNode, segOk);
         }
         if (hd.ngeneral > 0 && ncl_run > 0) eval_general_lines(sRec, ncl, nu, tau);
         MCALF_STAMP(3);

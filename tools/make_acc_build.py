@@ -32,15 +32,15 @@ rep("template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync>\n__global__ __l
     "__device__ unsigned long long g_acc[8192 * 32];\n#define CLK() __builtin_amdgcn_s_memtime()\n"
     "template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync>\n__global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {\n"
     "    unsigned long long accFold = 0, accBar = 0, accNode = 0, accDirect = 0;")
-rep("                                          double& farNode, unsigned long long segOk) {\n    const double A = rec[0], B = rec[1], x2c = rec[2];",
+rep("                                          double& farNode, unsigned long long segOk) {\n    const double A = tab[kLineLds + 1], B = tab[kLineLds + 2];",
     "                                          double& farNode, unsigned long long segOk, unsigned long long& accNode, unsigned long long& accDirect) {\n"
-    "    const unsigned long long c0 = __builtin_amdgcn_s_memtime();\n    const double A = rec[0], B = rec[1], x2c = rec[2];")
+    "    const unsigned long long c0 = __builtin_amdgcn_s_memtime();\n    const double A = tab[kLineLds + 1], B = tab[kLineLds + 2];")
 rep("    const unsigned doneLo = (unsigned)done, doneHi = (unsigned)(done >> 32);",
     "    const unsigned long long c1 = __builtin_amdgcn_s_memtime();\n    accNode += c1 - c0;\n"
     "    const unsigned doneLo = (unsigned)done, doneHi = (unsigned)(done >> 32);")
 rep("        fmac_inplace(tau[j], t, P);\n    }\n    }\n}", "        fmac_inplace(tau[j], t, P);\n    }\n    }\n    accDirect += __builtin_amdgcn_s_memtime() - c1;\n}")
-rep("eval_line(tabs + l * kTabPad, grec + l * kRecStride, nu, tau, nuNode, farNode, segOk);",
-    "eval_line(tabs + l * kTabPad, grec + l * kRecStride, nu, tau, nuNode, farNode, segOk, accNode, accDirect);")
+rep("eval_line(tabs + l * kTabPad, nu, tau, nuNode, farNode, segOk);",
+    "eval_line(tabs + l * kTabPad, nu, tau, nuNode, farNode, segOk, accNode, accDirect);")
 rep("            double* tabs = sTab + buf * (kLinesPerSync * kTabPad);\n            if (hasCoef) {",
     "            const unsigned long long f0 = CLK();\n            double* tabs = sTab + buf * (kLinesPerSync * kTabPad);\n            if (hasCoef) {")
 rep("            __syncthreads();\n            buf ^= 1;",
