@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: logL of EVERY row of BASELINE configs B, C, E against the plain-C/OpenMP oracle (and the numpy/scipy
+"""GPU box: logL of EVERY row of BASELINE configs B, C, D (all 32768 rows), E against the plain-C/OpenMP oracle (and the numpy/scipy
 oracle on a sample), written as one JSON object.  python tools/full_parity.py > gpurun_out/full_parity.json"""
 import json
 import os
@@ -23,7 +23,7 @@ def synth(kw, p):
 
 
 out = {}
-for cfg in (sys.argv[1:] or ["B", "C", "E"]):
+for cfg in (sys.argv[1:] or ["B", "C", "D", "E"]):
     kw, batch, seed = workloads.config(cfg, synth)
     P = workloads.draw_P(kw, batch, np.random.default_rng(seed), damped=2 if cfg == "E" else 0)
     prob = problem_from_kwargs(kw)
@@ -31,7 +31,7 @@ for cfg in (sys.argv[1:] or ["B", "C", "E"]):
         got = fit.loglike_batch(P)
         models = fit.model_batch(P[:64])
     t0 = time.time()
-    want = c_oracle.COracle(prob, threads=min(32, os.cpu_count() or 1)).loglike_batch(P)
+    want = c_oracle.COracle(prob, threads=min(16, os.cpu_count() or 1)).loglike_batch(P)
     tc = time.time() - t0
     k = min(batch, 256)
     wnp = o.loglike_batch(prob, P[:k])
