@@ -134,8 +134,9 @@ int mcalf_chi2_batch(mcalf_ctx* ctx, const double* P, int64_t batch, double* chi
 int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batch, int32_t which, double* flux);
 
 /* Row blocks a batch is issued in (0 = automatic [default], n <= 8 = exactly n).  Automatic means ONE block
- * for the *_device entries (the persistent fused kernel leaves no launch tail worth filling; measured) and FOUR
- * for the host-pointer entries with large batches, where block k+1's H2D copy and per-sample set-up run under
+ * for the *_device entries (the persistent fused kernel leaves no launch tail worth filling; measured) and, for
+ * the host-pointer entries with large batches, a small first block followed by larger ones (1:1:2:4 of the rows
+ * for pageable input, 1:7 for page-locked input), so that block k+1's H2D copy and per-sample set-up run under
  * block k's kernel and block k's D2H copy under block k+1's.  With more than one block in a *_device call the
  * blocks after the first run on context-owned streams between a fork event recorded on the caller's stream and
  * join events that stream waits for: the call keeps plain stream semantics (and can be captured into a

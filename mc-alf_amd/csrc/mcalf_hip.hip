@@ -1037,6 +1037,8 @@ struct mcalf_ctx {
     // auxiliary streams (fork / join through events), so that the set-up kernel and the first workgroups of
     // block k+1 run in the tail of block k.  chunks_req: 0 = automatic, n = exactly n blocks (1 = off).
     int chunks_req = 0;
+    int host_plan[kMaxChunks] = {};            // MCALF_HOST_PLAN: relative sizes of the row blocks of the pipelined
+    int host_plan_n = 0;                       // host-pointer entry (0 = the built-in plans)
     int num_cu = 256;
     int persist = 1;                    // fused kernel as a persistent grid (MCALF_PERSIST=0: one workgroup per item)
     unsigned int* d_queue = nullptr;    // [kMaxChunks] work-item queues of the persistent kernel
@@ -1360,6 +1362,16 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         HIP_TRY(ctx, hipMemset(ctx->d_queue, 0, kMaxChunks * sizeof(unsigned int)));
         const char* pe = std::getenv("MCALF_PERSIST");
         if (pe && *pe) ctx->persist = std::atoi(pe) != 0;
+        if (const char* hp = std::getenv("MCALF_HOST_PLAN")) {      // e.g. "1,3,4": relative block sizes (diagnostic)
+            int n = 0;
+            for (const char* q = hp; *q && n < kMaxChunks;) {
+                const int v = std::atoi(q);
+                if (v > 0) ctx->host_plan[n++] = v;
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+            if (n > 0) ctx->host_plan_n = n;
+        }
         const char* env = std::getenv("MCALF_CHUNKS");            // 0 / unset: automatic; n: exactly n row blocks
         if (env && *env) {
             const int v = std::atoi(env);
@@ -1621,16 +1633,40 @@ static bool is_pinned_host(const void* p) {
 static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly,
                               int fill, double* out_scalar) {
     int rc;
-    int nchunks = ctx->chunks_req > 0 ? ctx->chunks_req : 4;
-    if (nchunks > kMaxChunks) nchunks = kMaxChunks;
+    // Row blocks: an explicit request gives equal blocks; the automatic plan is a SMALL first block (the GPU starts
+    // after one eighth of the input has arrived) followed by larger ones (large launches run the persistent grid
+    // and leave fewer tails).  Measured on MI355X, config C (device-resident 0.251 ms per batch): pageable input
+    // 1:1:2:4 0.311 ms, 1:3:4 0.319, 2:6 0.320, four equal blocks 0.333, one block 0.351; page-locked input (no
+    // staging copy on the host thread) 1:7 0.297, 2:6 0.301, 1:1:2:4 0.307, four equal blocks 0.321.
+    const bool pin_in = is_pinned_host(P), pin_out = is_pinned_host(out_scalar);
+    int weights[kMaxChunks];
+    int nchunks = 0;
+    if (ctx->chunks_req > 0) {
+        for (nchunks = 0; nchunks < ctx->chunks_req && nchunks < kMaxChunks; ++nchunks) weights[nchunks] = 1;
+    } else if (ctx->host_plan_n > 0) {
+        for (nchunks = 0; nchunks < ctx->host_plan_n; ++nchunks) weights[nchunks] = ctx->host_plan[nchunks];
+    } else if (pin_in) {
+        weights[0] = 1; weights[1] = 7; nchunks = 2;
+    } else {
+        weights[0] = 1; weights[1] = 1; weights[2] = 2; weights[3] = 4; nchunks = 4;
+    }
     if ((int64_t)nchunks > batch) nchunks = (int)batch;
     if (ctx->profiling) nchunks = 1;
+    int64_t bounds[kMaxChunks + 1];
+    {
+        int total = 0, run = 0;
+        for (int c = 0; c < nchunks; ++c) total += weights[c];
+        bounds[0] = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            run += weights[c];
+            bounds[c + 1] = batch * run / total;
+        }
+    }
     if ((rc = ensure_aux(ctx, 1))) return rc;
     const bool reduces = (mode == kModeLogL || mode == kModeChi2);
     if (reduces && ctx->ntiles > 1 && (rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4)))
         return rc;
     if ((rc = grow_sample_ws(ctx, batch))) return rc;
-    const bool pin_in = is_pinned_host(P), pin_out = is_pinned_host(out_scalar);
     const size_t need = (pin_in ? 0 : (size_t)batch * rowlen) + (pin_out ? 0 : (size_t)batch);
     if (need > ctx->cap_stage) {
         if (ctx->h_stage) HIP_TRY(ctx, hipHostFree(ctx->h_stage));
@@ -1642,7 +1678,8 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
     double* stage_out = pin_out ? out_scalar : ctx->h_stage + (pin_in ? 0 : (size_t)batch * rowlen);
     hipStream_t streams[2] = {ctx->stream, ctx->aux[0]};
     for (int c = 0; c < nchunks; ++c) {
-        const int64_t r0 = chunk_begin(batch, nchunks, c), n = chunk_begin(batch, nchunks, c + 1) - r0;
+        const int64_t r0 = bounds[c], n = bounds[c + 1] - r0;
+        if (n == 0) continue;
         hipStream_t st = streams[c & 1];
         const double* src = P + (size_t)r0 * rowlen;
         if (!pin_in) {
