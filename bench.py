@@ -267,7 +267,12 @@ def main():
     def measure(fn, k, red_dev):
         """Median over repeated timed passes (each pass = exactly k steps); every pass time is the MAX over ranks."""
         first = timed_pass(fn, k)
-        npass = 1 if first * 1e3 >= MIN_PASS_MS else min(15, 2 * int(math.ceil(MIN_PASS_MS / max(first * 1e3, 1e-3))) + 1)
+        ref = first
+        if use_dist:                                     # every rank must run the SAME number of passes (collectives inside)
+            t1 = torch.tensor([first], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+            ref = float(t1.item())
+        npass = 1 if ref * 1e3 >= MIN_PASS_MS else min(15, 2 * int(math.ceil(MIN_PASS_MS / max(ref * 1e3, 1e-3))) + 1)
         times = [first] + [timed_pass(fn, k) for _ in range(npass - 1)]
         t = torch.tensor(times, dtype=torch.float64, device=red_dev)
         if use_dist:
