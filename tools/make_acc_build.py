@@ -55,6 +55,6 @@ rep('extern "C" int mcalf_diag_read_dbg',
     'extern "C" int mcalf_diag_read_dbg')
 open(os.path.join(work, "acc.hip"), "w").write(s)
 out = os.path.join(root, "build", "abl", "stamps.so")
-cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DMCALF_STAMPS=1", "-o", out, "acc.hip"]
+cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DMCALF_STAMPS=1"] + (["-DMCALF_COUNT_INTERP=1"] if os.environ.get("MCALF_COUNT_INTERP") else []) + ["-o", out, "acc.hip"]
 subprocess.check_call(cmd, cwd=work)
 print("built", out)
