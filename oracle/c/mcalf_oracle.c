@@ -1,5 +1,6 @@
 /* mcalf_oracle.c -- plain-C restatement of the MC-ALF numpy likelihood path.  TEST INFRASTRUCTURE ONLY:
- * it cross-checks the numpy/scipy oracle with an independent Faddeeva implementation and serves as the
+ * it cross-checks the numpy/scipy oracle with a Faddeeva implementation independent of scipy's (the same algorithm as the
+ * device's rarely used general path, so not independent of THAT; the device's hot table path is a different method) and serves as the
  * multi-threaded CPU baseline of bench.py.  Never linked into or called by the product (mc-alf_amd/).
  *
  * Follows /root/reference/mcalf/routines/hires_fitter.py:

@@ -1,4 +1,4 @@
-"""CPU: the plain-C oracle (independent Faddeeva implementation) against the numpy/scipy oracle, the
+"""CPU: the plain-C oracle (a Faddeeva implementation independent of scipy's wofz) against the numpy/scipy oracle, the
 reference's fixtures and mpmath."""
 import os
 
