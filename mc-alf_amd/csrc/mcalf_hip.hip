@@ -45,8 +45,7 @@ constexpr int kLineLds = kZFLds + VT_FDEG + 1;   // [uthr, A, B] of the line, ri
 static_assert(kLineLds + 3 <= kTabPad && (kLineLds % 2) == 1, "line constants pair up with the last zone-F coefficient");
 // Lines folded per workgroup barrier of the component loop: 4 or 5, chosen per context (whichever needs fewer
 // barriers for the context's largest line count; measured on MI355X: config C, 20-24 lines, -0.8 % with 5;
-// config E, 16 lines, +1.3 % with 5).
-constexpr int kLinesPerSyncMax = 5;
+// config E, 16 lines, +1.3 % with 5).  The fused kernel is instantiated for both (fused_kernel_ptr).
 static_assert(kBlock == 64 * VT_INODES, "one interpolation weight per thread");
 static_assert(kPpt == 8, "the skip tests of eval_line treat the eight segments of a wave as two halves");
 static_assert(VT_NTOT <= kBlock - 64 && (kZ0Lds % 2) == 0 && (kZFLds % 2) == 0 && (kTabPad % 2) == 0, "LDS table layout");
