@@ -112,6 +112,22 @@ def usable_cpus():
     return n
 
 
+def pick_workload(world, config=None, scaling=None):
+    """Default workload of a run: one GPU -> BASELINE config C (the largest single-GPU configuration); several ->
+    config D (32768 live points job-wide) as a strong-scaling job, the rows split over the ranks."""
+    return config or ("C" if world == 1 else "D"), scaling or "strong"
+
+
+def rows_per_rank(job_batch, world, scaling):
+    """Rows each rank evaluates: the configuration's batch split over the ranks (strong) or repeated on every rank
+    (weak)."""
+    if scaling == "strong":
+        if job_batch % world:
+            raise SystemExit(f"--scaling strong: batch {job_batch} is not a multiple of {world} ranks")
+        return job_batch // world
+    return job_batch
+
+
 def load_profile_json(name, config):
     try:
         with open(os.path.join(ROOT, "profiles", name)) as fh:
@@ -155,8 +171,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
-    config = args.config or ("C" if world == 1 else "D")
-    scaling = args.scaling or "strong"
+    config, scaling = pick_workload(world, args.config, args.scaling)
     # MCALF_BENCH_FORCE_DIST=1 (with torch.distributed.run --nproc-per-node 1) runs the N>1 code path --
     # process group, RCCL gather ring, barrier, all_reduce -- on a single rank: a one-GPU check of the
     # collective plumbing the driver's multi-GPU runs use.
@@ -178,12 +193,7 @@ def main():
     kw, job_batch, seed = workloads.config(config, hip_synth)
     if args.batch:
         job_batch = args.batch
-    if scaling == "strong":
-        if job_batch % world:
-            raise SystemExit(f"--scaling strong: batch {job_batch} is not a multiple of {world} ranks")
-        batch = job_batch // world                       # per-rank rows; the job-wide batch stays the config's
-    else:
-        batch = job_batch
+    batch = rows_per_rank(job_batch, world, scaling)     # per-rank rows; strong: the job-wide batch stays the config's
     damped = 2 if config == "E" else 0
     # every rank draws the job-wide matrix from one seed and keeps its contiguous row block
     P_all = workloads.draw_P(kw, batch * world, np.random.default_rng(seed), damped=damped)
