@@ -136,6 +136,46 @@ def load_profile_json(name, config):
         return None
 
 
+def library_source_hash(lib):
+    """The sha256 prefix of the kernel sources the loaded library was built from (mcalf_version(): '... src <hash>')."""
+    ver = lib.mcalf_version().decode()
+    return ver.rsplit(" src ", 1)[1] if " src " in ver else "unstamped"
+
+
+def stamped(entry, lib_hash):
+    """A PMC-derived entry of profiles/*.json is only quoted when it was measured on the kernel that is running:
+    (entry, None) when its `source_hash` equals the library's, else (None, why)."""
+    if not entry:
+        return None, "no PMC record for this configuration under profiles/"
+    have = entry.get("source_hash")
+    if have != lib_hash or lib_hash == "unstamped":
+        return None, (f"profiles/ record was measured on kernel sources {have}, the loaded library is {lib_hash}: "
+                      "stale counters are not quoted (re-run tools/r03_profiles.sh)")
+    return entry, None
+
+
+def issue_model(iss, kern_ms):
+    """Instruction-issue bound of the fused kernel from the PMC instruction counts (profiles/pmc.json `issue`).
+
+    A wave issues at most one instruction at a time and the SIMD's arbiter one per class per cycle, so with W
+    waves per SIMD a launch cannot finish before  max(per-class pipe time, serial issue time of a wave / overlap):
+      t_pipe  = wave-instructions of the busiest pipe on a SIMD x its measured cycles per instruction
+      t_issue = all wave-instructions of a SIMD x the measured issue interval of a single wave / W
+    cycles per instruction come from tools/micro/issue_rate.hip on this pool (`cycles`); `frac` = bound / measured."""
+    simds = iss["simds"]
+    clk = iss["clock_mhz"] * 1e6
+    cyc = iss["cycles"]
+    per_simd = {k: iss["insts"][k] / simds for k in iss["insts"]}
+    t_pipe = {k: per_simd[k] * cyc["pipe"][k] / clk * 1e3 for k in per_simd if k in cyc["pipe"]}
+    t_issue = sum(per_simd[k] * cyc["wave"][k] for k in per_simd if k in cyc["wave"]) / iss["waves_per_simd"] / clk * 1e3
+    bound = max(max(t_pipe.values()), t_issue)
+    return {"bound": "instruction issue", "unit": "ms", "achieved": kern_ms, "peak": bound, "frac": bound / kern_ms,
+            "pipe_ms": t_pipe, "serial_issue_ms": t_issue, "waves_per_simd": iss["waves_per_simd"],
+            "wave_instructions_per_launch": iss["insts"], "cycles_per_instruction": cyc,
+            "note": "frac = the time the measured instruction stream needs at the measured issue rates over the kernel's "
+                    "duration: near 1 means only removing instructions makes the kernel faster"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +202,7 @@ def main():
                          "kernels and one grouped ncclSend/ncclRecv exchange on the launch stream)")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer (PCIe-inclusive) passes")
     ap.add_argument("--no-strong-ref", action="store_true", help="N=1: skip the config-D-on-one-GPU reference")
+    ap.add_argument("--no-model-leg", action="store_true", help="N=1: skip the model-output (reconstruct_spec) passes")
     ap.add_argument("--inflight", type=int, default=1,
                     help="diagnostic: independent batches kept in flight (contexts + streams); 1 = the headline")
     args = ap.parse_args()
@@ -199,6 +240,12 @@ def main():
     P_all = workloads.draw_P(kw, batch * world, np.random.default_rng(seed), damped=damped)
     P_host = np.ascontiguousarray(P_all[rank * batch:(rank + 1) * batch])
     del P_all
+    if os.environ.get("MCALF_BENCH_SORT") in ("asc", "desc"):
+        # diagnostic only (never set by the driver): rows ordered by their ncomp slot, to measure what an ordered
+        # hand-out of the work items would buy
+        start = int(len(np.atleast_1d(kw["specres"])) > 1) + int(len(np.atleast_1d(kw.get("contval", [1.0]))) > 1)
+        key = P_host[:, start] * (1.0 if os.environ["MCALF_BENCH_SORT"] == "asc" else -1.0)
+        P_host = np.ascontiguousarray(P_host[np.argsort(key, kind="stable")])
     fit = mcalf_amd.als_fitter(None, device=local_rank, **kw)
     if args.chunks >= 0:
         fit.set_chunks(args.chunks)
@@ -223,7 +270,7 @@ def main():
             _lib.check(f2._lib.mcalf_reserve(f2._ctx, batch), f2._ctx)
             s2 = torch.cuda.Stream()
             extra.append((f2, s2, torch.empty(batch, dtype=torch.float64, device=dev)))
-    inlib = mdist.InLibGather(fit, batch, dev) if (use_dist and args.gather == "inlib" and not rehearsal) else None
+    inlib = mdist.InLibGather(fit, batch * world, dev) if (use_dist and args.gather == "inlib" and not rehearsal) else None
     turn = [0]
     launch = fit._lib.mcalf_loglike_batch_device
     ctx, pP = fit._ctx, dP.data_ptr()
@@ -258,8 +305,7 @@ def main():
     def fence():
         if use_dist:
             if inlib is not None:
-                torch.cuda.synchronize()                 # the exchange is on the launch stream
-                gathered[0] = inlib.all
+                gathered[0] = inlib.finish(stream)       # joins the exchanges of the library's side stream
             else:
                 gathered[0] = plan.finish()              # every outstanding gather has landed on rank 0
             dist.barrier()
@@ -298,7 +344,7 @@ def main():
     if use_dist:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     comp_pix_job, line_pix_job = (float(v) for v in tot.tolist())
-    logL_dev = last_out[0].cpu().numpy()
+    logL_dev = (inlib.local if inlib is not None else last_out[0]).cpu().numpy()
     gather_check = None
     if use_dist and rank == 0 and gathered[0] is not None:
         # the vector rank 0 holds after the last gather: its own block must be what it computed, and every
@@ -358,6 +404,42 @@ def main():
                       "ms_per_step": tD / kD * 1e3, "value": float(ncD.sum()) * npix * kD / tD}
         del dPD, outD
 
+    # Model-output entry (reconstruct_spec for the whole batch, hires_fitter.py:409-449; consumer cli.py:414-418):
+    # the only mode in which HBM bytes matter -- 8 * npix B per live point are written
+    model_leg = None
+    if world == 1 and not args.no_model_leg and not extra:
+        dflux = torch.empty((batch, npix), dtype=torch.float64, device=dev)
+        model_fn = fit._lib.mcalf_model_batch_device
+
+        def stepM():
+            rc = model_fn(ctx, pP, batch, 0, dflux.data_ptr(), st)
+            if rc:
+                _lib.check(rc, ctx)
+        for _ in range(3):
+            stepM()
+        kM = max(5, args.steps // 4)
+        tM, _ = measure(stepM, kM, red_dev)
+        kmM, nlM = C.c_double(0.0), C.c_int32(0)
+        _lib.check(fit._lib.mcalf_profile_begin(fit._ctx, kM), fit._ctx)
+        for _ in range(kM):
+            stepM()
+        fence()
+        _lib.check(fit._lib.mcalf_profile_end(fit._ctx, C.byref(kmM), C.byref(nlM)), fit._ctx)
+        # one row checked against the log-likelihood entry: logL recomputed on the host from the model spectrum
+        row = dflux[0].cpu().numpy()
+        ispec2 = 1.0 / fit.obj_noise ** 2
+        ll0 = -0.5 * np.nansum(ispec2 * (fit.obj - row) ** 2 - np.log(ispec2) + np.log(2.0 * np.pi))
+        bytes_alg = (8 * ndim + 8 * npix) * batch + 8 * npix          # parameters in, model out, frequencies once
+        model_leg = {"entry": "mcalf_model_batch_device (targonly = 0), model spectra left in HBM", "steps": kM,
+                     "ms_per_step": tM / kM * 1e3, "kernel_ms": kmM.value if nlM.value else None,
+                     "value": comp_pix * kM / tM, "unit": "evals/s",
+                     "algorithmic_bytes_per_launch": bytes_alg,
+                     "hbm_gbs": bytes_alg / ((kmM.value if nlM.value else tM / kM * 1e3) * 1e-3) / 1e9,
+                     "hbm_frac": bytes_alg / ((kmM.value if nlM.value else tM / kM * 1e3) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "kernel_ratio_to_logL_mode": (kmM.value / kern_ms) if nlM.value else None,
+                     "logL_from_model_row0_minus_logL_entry": float(ll0 - logL_dev[0])}
+        del dflux
+
     out = None
     if rank == 0:
         n_half = fit.info.n_cap
@@ -365,11 +447,13 @@ def main():
         alg_flops = 40.0 * line_pix + (31 + 4 * n_half) * npix * batch
         ach_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
         std_batch = not args.batch and (world == 1 or scaling == "strong")
-        tr = load_profile_json("traffic.json", config) if std_batch and world == 1 else None
-        pmc = load_profile_json("pmc.json", config) if std_batch and world == 1 else None
+        lib_hash = library_source_hash(fit._lib)
+        tr, tr_note = stamped(load_profile_json("traffic.json", config) if std_batch and world == 1 else None, lib_hash)
+        pmc, pmc_note = stamped(load_profile_json("pmc.json", config) if std_batch and world == 1 else None, lib_hash)
         ms_per_step = elapsed / args.steps * 1e3
         out = {
-            "metric": "component-pixel Voigt evals/s (sum_s ncomp_s * npix / t), logL batch on MI355X",
+            "metric": "component-pixel Voigt evals/s (sum_s ncomp_s * npix / t), logL batch on MI355X, parameters and "
+                      "logL device-resident (the PCIe-inclusive host-pointer rate of SURVEY.md 8(d) is value_host_api)",
             "value": comp_pix_job * args.steps / elapsed,
             "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -392,31 +476,50 @@ def main():
             "kernel_ms": kern_ms,
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": tr["traffic_bytes_per_launch"] if tr else None,
+                         "traffic_note": tr_note,
                          "kernel": "mcalf_fused_kernel (one launch over the whole batch)",
+                         "kernel_source_hash": lib_hash,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "the fused path is FP64-VALU bound, not HBM bound (arithmetic intensity > 1e3 FLOP/B, "
                                  "SURVEY.md 8d): the HBM fraction is ~1e-3 by construction; see roofline_valu"},
-            "roofline_valu": {"bound": "fp64_valu", "achieved": alg_flops / (kern_ms * 1e-3) / 1e12,
-                              "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": alg_flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+            "roofline_valu": {"bound": "fp64_valu", "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "throughput_equivalent": alg_flops / (kern_ms * 1e-3) / 1e12,
+                              "throughput_equivalent_frac": alg_flops / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                               "algorithmic_flops_per_launch": alg_flops,
-                              "note": "frac prices SURVEY 8(d)'s nominal 40 FLOP per line-pixel; far-wing interpolation "
-                                      "skips most of those evaluations, so frac is a throughput-equivalent, not pipe "
-                                      "utilisation -- valu_busy (PMC) is the utilisation"},
+                              "note": "throughput_equivalent prices SURVEY 8(d)'s nominal 40 FLOP per line-pixel; the "
+                                      "far-wing interpolation legitimately skips most of those evaluations, so it is "
+                                      "NOT a bound (it exceeds 1 at config E) and not pipe utilisation: `achieved` / "
+                                      "`frac` are the FP64 operations the pipes executed (PMC instruction mix), "
+                                      "valu_busy the share of cycles the vector pipe was issuing",
+                              "pmc_note": pmc_note},
         }
         if pmc:
             out["roofline_valu"].update({k: pmc[k] for k in ("valu_busy", "executed_flops_per_launch", "source") if k in pmc})
             if "executed_flops_per_launch" in pmc:
-                out["roofline_valu"]["executed_tflops"] = pmc["executed_flops_per_launch"] / (kern_ms * 1e-3) / 1e12
+                ex = pmc["executed_flops_per_launch"] / (kern_ms * 1e-3) / 1e12
+                out["roofline_valu"].update({"achieved": ex, "frac": ex / FP64_VALU_PEAK_TFLOPS})
+            if "issue" in pmc:
+                out["roofline_issue"] = issue_model(pmc["issue"], kern_ms)
         if host_api:
             out["value_host_api"] = host_api["value"]
             out["ms_per_step_host_api"] = host_api["ms_per_step"]
             out["host_api"] = host_api
         if strong_ref:
+            # what 8 GPUs can reach at best when each gets this batch and the job is config D: the one-GPU time of
+            # the 32768 rows over 8 x this step (no collective yet)
+            strong_ref["ceiling_8gpu_speedup"] = strong_ref["ms_per_step"] / ms_per_step
+            strong_ref["ceiling_8gpu_efficiency"] = strong_ref["ms_per_step"] / (8.0 * ms_per_step)
             out["strong_scaling_reference"] = strong_ref
+        if model_leg:
+            out["model_output"] = model_leg
+        ll = fit.last_launch()
+        out["launch"] = {"persistent": bool(ll.persistent), "grid": ll.grid, "items": ll.items,
+                         "lines_per_sync": ll.lines_per_sync, "ordered_handout": os.environ.get("MCALF_ORDER", "1") != "0"}
         if use_dist:
             out["rccl_ranks"] = rccl_ranks
-            out["gather"] = ("library (mcalf_loglike_gather_device: grouped ncclSend/ncclRecv on the launch stream)"
+            out["gather"] = ("library (mcalf_loglike_gatherv_device: kernels on the launch stream, grouped ncclSend/ncclRecv "
+                             "on the context's exchange stream, two buffer pairs in flight"
+                             + ("; ONE rank: the exchange is a device-to-device copy, no RCCL call is made)" if rccl_ranks == 1 else ")")
                              if inlib is not None else "torch.distributed.gather, two buffers in flight")
         if args.cpu_seconds > 0 and world == 1:          # the CPU baseline is an N=1 figure (rank 0 only)
             vals, dt, done = cpu_baseline(kw, P_host, args.cpu_seconds)

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MCALF_ABI_VERSION 1
+#define MCALF_ABI_VERSION 2   /* 2: mcalf_last_launch, gatherv / overlap / join, version string carries the source hash */
 
 enum {
     MCALF_OK = 0,
@@ -116,6 +116,8 @@ int mcalf_create(const mcalf_spec* spec, mcalf_ctx** out);
 void mcalf_destroy(mcalf_ctx* ctx);
 int mcalf_info(const mcalf_ctx* ctx, mcalf_info_t* info);
 const char* mcalf_last_error(const mcalf_ctx* ctx);
+/* "mcalf_hip <version> (gfx950, abi <n>) src <hash>": <hash> = first 16 hex digits of the sha256 over the kernel
+ * sources the library was built from ("unstamped" for a build that did not go through mc-alf_amd/build.py). */
 const char* mcalf_version(void);
 
 /* Pre-size the context's device workspaces for batches up to `batch` rows so that later
@@ -155,6 +157,29 @@ int mcalf_loglike_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, 
 int mcalf_model_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, int32_t targonly,
                              double* dflux, void* stream);
 
+/* What the LAST call of this context actually did (tests and benchmarks assert on the path taken instead of
+ * inferring it from batch sizes).  `path`: which entry plan ran; the remaining fields describe the last fused-kernel
+ * launch of that call. */
+enum {
+    MCALF_PATH_NONE = 0,          /* no call yet                                                              */
+    MCALF_PATH_DEVICE = 1,        /* a *_device entry (caller's device pointers and stream)                   */
+    MCALF_PATH_HOST_ZEROCOPY = 2, /* host pointers, small call: theta / logL through the page-locked mapped block */
+    MCALF_PATH_HOST_PIPELINED = 3,/* host pointers, large scalar-output call: row blocks over two streams     */
+    MCALF_PATH_HOST_STAGED = 4    /* host pointers, model output: H2D, launch, D2H on the context's stream    */
+};
+typedef struct {
+    int32_t path;           /* MCALF_PATH_*                                                                   */
+    int32_t row_blocks;     /* row blocks the call was issued in                                              */
+    int32_t persistent;     /* 1: the last fused launch ran the persistent grid with the work-item queue      */
+    int32_t grid;           /* workgroups of the last fused launch                                            */
+    int64_t items;          /* work items (live points x tiles) of the last fused launch                      */
+    int32_t lines_per_sync; /* lines folded per workgroup barrier (4 or 5)                                    */
+    int32_t selfhalo;       /* 1: single-tile spectrum, halo entries are copies of the tile's own pixels      */
+    int32_t pinned_in;      /* host-pointer entries: the parameter rows were page-locked caller memory        */
+    int32_t pinned_out;     /* host-pointer entries: the result array was page-locked caller memory           */
+} mcalf_launch_info_t;
+int mcalf_last_launch(const mcalf_ctx* ctx, mcalf_launch_info_t* info);
+
 /* Measurement aid: between _begin and _end every fused-kernel launch of this context is bracketed by
  * HIP events on the stream it is launched on (at most max_launches of them); _end waits for them and
  * returns the mean duration in milliseconds of mcalf_fused_kernel alone (the small per-sample set-up
@@ -184,20 +209,42 @@ int mcalf_loglike_cube_batch_device(mcalf_ctx* ctx, const double* dcube, int64_t
  * points: PolyChord's MPI workers cli.py:110, jaxns' vmap cli.py:275-280).  One process per GPU, each with its own
  * context; the context owns an RCCL communicator (xGMI on one node).  Rank 0 obtains a 128-byte id with
  * mcalf_comm_unique_id and hands it to the other ranks by any means (MPI, torch.distributed, a file); every rank
- * then calls mcalf_comm_init (collective).  mcalf_loglike_gather_device evaluates the rank's own contiguous block
- * of live points and enqueues, on the same stream and right behind the kernels, ONE grouped send / receive
- * exchange that lands every rank's logL block in dlogL_all on `root` (block r at offset r * batch_local; every
- * rank passes the same batch_local; dlogL_all may be NULL on the other ranks).  Nothing synchronises: the call
- * returns as soon as the work is enqueued.  Because a live point's arithmetic does not depend on the shard, the
- * gathered vector equals the single-GPU result bit for bit.  RCCL is loaded at run time by the first of these
- * calls (MCALF_ERR_COMM if it is absent); single-GPU use never touches it. */
+ * then calls mcalf_comm_init (collective).
+ *
+ * mcalf_loglike_gatherv_device evaluates the rank's own contiguous block of live points on `stream` and enqueues ONE
+ * grouped send / receive exchange (what ncclGather is) that lands every rank's logL block in dlogL_all on `root`:
+ * block r at offset counts[0] + ... + counts[r-1].  `counts` is a HOST array [nranks] that every rank passes
+ * identically (ragged shards allowed, zeros allowed; counts[rank] must equal batch_local); NULL means every rank
+ * evaluates batch_local rows (mcalf_loglike_gather_device is that form).  dlogL_all may be NULL on the other ranks.
+ * The exchange runs on a context-owned stream behind an event of `stream`, so the root's NEXT kernels never wait for
+ * its peers.  By default the call ends with `stream` waiting for the exchange (plain stream semantics: what follows
+ * on `stream` sees the gathered vector).  With mcalf_comm_set_overlap(ctx, 1) it does not: the exchange of call k
+ * overlaps the kernels of call k+1, the caller alternates between TWO (dlogL_local, dlogL_all) buffer pairs -- the
+ * library orders call k+2 behind exchange k -- and calls mcalf_comm_join(ctx, stream) before it consumes a result.
+ * Nothing synchronises the host.  Because a live point's arithmetic does not depend on the shard, the gathered
+ * vector equals the single-GPU result bit for bit.
+ *
+ * Errors never leave a peer waiting:
+ *   - MCALF_ERR_INVALID from the argument checks: nothing was enqueued on this rank (a programming error that every
+ *     rank of a correct SPMD caller makes alike).
+ *   - a LOCAL failure (workspace growth, kernel launch): the rank still takes its part in the exchange with a block
+ *     of NaNs, then returns its error code; the peers complete, the root sees NaN rows for that rank, and the
+ *     communicator stays usable.
+ *   - a failure inside the exchange itself (RCCL / event calls): the communicator is aborted (ncclCommAbort),
+ *     MCALF_ERR_COMM is returned and every later gather is refused until mcalf_comm_destroy + mcalf_comm_init.
+ * RCCL is loaded at run time by the first of these calls (MCALF_ERR_COMM if it is absent; MCALF_RCCL_LIB names an
+ * explicit library); single-GPU use never touches it. */
 #define MCALF_COMM_ID_BYTES 128
 int mcalf_comm_unique_id(void* id128);
 int mcalf_comm_init(mcalf_ctx* ctx, const void* id128, int32_t nranks, int32_t rank);
 int mcalf_comm_info(const mcalf_ctx* ctx, int32_t* nranks, int32_t* rank);
 int mcalf_comm_destroy(mcalf_ctx* ctx);
+int mcalf_comm_set_overlap(mcalf_ctx* ctx, int32_t on);
+int mcalf_comm_join(mcalf_ctx* ctx, void* stream);
 int mcalf_loglike_gather_device(mcalf_ctx* ctx, const double* dP, int64_t batch_local, double* dlogL_local,
                                 double* dlogL_all, int32_t root, void* stream);
+int mcalf_loglike_gatherv_device(mcalf_ctx* ctx, const double* dP, int64_t batch_local, double* dlogL_local,
+                                 double* dlogL_all, const int64_t* counts, int32_t root, void* stream);
 
 /* Diagnostic: out[i] = H(x[i], y[i]) = Re w(x + i y) evaluated by the device Voigt function
  * (host pointers).  device = -1 for the current device. */

@@ -66,6 +66,23 @@ class mcalf_info_t(C.Structure):
     ]
 
 
+MCALF_PATH_NONE, MCALF_PATH_DEVICE, MCALF_PATH_HOST_ZEROCOPY, MCALF_PATH_HOST_PIPELINED, MCALF_PATH_HOST_STAGED = range(5)
+
+
+class mcalf_launch_info_t(C.Structure):
+    _fields_ = [
+        ("path", C.c_int32),
+        ("row_blocks", C.c_int32),
+        ("persistent", C.c_int32),
+        ("grid", C.c_int32),
+        ("items", C.c_int64),
+        ("lines_per_sync", C.c_int32),
+        ("selfhalo", C.c_int32),
+        ("pinned_in", C.c_int32),
+        ("pinned_out", C.c_int32),
+    ]
+
+
 # every symbol include/mcalf_hip.h declares: name -> (restype, argtypes)
 _PD = C.POINTER(C.c_double)
 _CTX = C.c_void_p
@@ -84,6 +101,7 @@ SYMBOLS = {
     "mcalf_onecomp_batch": (C.c_int, [_CTX, _PD, C.c_int64, C.c_int32, _PD]),
     "mcalf_loglike_batch_device": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "mcalf_model_batch_device": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mcalf_last_launch": (C.c_int, [_CTX, C.POINTER(mcalf_launch_info_t)]),
     "mcalf_profile_begin": (C.c_int, [_CTX, C.c_int32]),
     "mcalf_profile_end": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mcalf_scale_cube_batch": (C.c_int, [_CTX, _PD, _PD, _PD, C.c_int64, C.c_int32, _PD]),
@@ -94,7 +112,11 @@ SYMBOLS = {
     "mcalf_comm_init": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32]),
     "mcalf_comm_info": (C.c_int, [_CTX, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mcalf_comm_destroy": (C.c_int, [_CTX]),
+    "mcalf_comm_set_overlap": (C.c_int, [_CTX, C.c_int32]),
+    "mcalf_comm_join": (C.c_int, [_CTX, C.c_void_p]),
     "mcalf_loglike_gather_device": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mcalf_loglike_gatherv_device": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
+                                               C.c_int32, C.c_void_p]),
     "mcalf_voigt_hjerting": (C.c_int, [_PD, _PD, C.c_int64, _PD, C.c_int32]),
     "mcalf_voigt_hjerting_nodes": (C.c_int, [_PD, _PD, C.c_int64, _PD, C.c_int32]),
 }

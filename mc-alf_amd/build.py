@@ -1,6 +1,7 @@
 """Build libmcalf_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -8,6 +9,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SOURCES = ["mcalf_hip.hip"]
 HEADERS = ["voigt_device.h", "voigt_tables.h", os.path.join("..", "..", "include", "mcalf_hip.h")]
+HASHED = ["mcalf_hip.hip", "voigt_device.h", "voigt_tables.h"]
 TARGET = os.path.join(CSRC, "libmcalf_hip.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
 
@@ -19,12 +21,23 @@ def _stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources (mcalf_hip.hip, voigt_device.h, voigt_tables.h), 16 hex digits.  The library
+    carries it (mcalf_version()), the PMC-derived files under profiles/ are stamped with it, and bench.py drops
+    their figures when the two differ -- a kernel edit cannot ship stale utilisation numbers."""
+    h = hashlib.sha256()
+    for f in HASHED:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP library if it is missing or older than its sources."""
     if not force and not _stale():
         return TARGET
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + ["-o", TARGET] + SOURCES
+    cmd = [hipcc] + FLAGS + [f'-DMCALF_SRC_HASH="{source_hash()}"', "-o", TARGET] + SOURCES
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)

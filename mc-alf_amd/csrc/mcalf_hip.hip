@@ -71,7 +71,7 @@ enum Mode : int { kModeLogL = 0, kModeModel = 1, kModeChi2 = 2, kModeOneComp = 3
 struct LineDev {
     double wrest_cm;  // wrest/1e8                 hires_fitter.py:376
     double f;
-    double gamma;
+    double gamma4pi;  // gamma / (4 pi)            hires_fitter.py:361 (a = gamma4pi / dnu)
     double nujk;      // ccgs / wrest_cm           hires_fitter.py:359
 };
 
@@ -121,6 +121,10 @@ struct KArgs {
     // persistent fused kernel: work items (live point x tile) of this launch and its item queue
     int nitems, persist;
     unsigned int* queue;    // reset to 0 by the set-up kernel of the same launch
+    // Hand-out order of the persistent kernel (single-tile spectra): ticket t of the queue is live point
+    // order[t] -- the live points sorted by their component count, longest first (written by one extra workgroup
+    // of the set-up kernel); nullptr = ticket order.  Scheduling only: a live point's arithmetic does not depend on who evaluates it when.
+    int* order;
 };
 
 // LDS flux tile, "mod-8 planar": element i lives in plane (i & 7) at index (i >> 3).  The convolution
@@ -168,11 +172,13 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// Butterfly sum over the 64 lanes of a wave, result in every lane (no LDS, no barrier).
+// Sum over the 64 lanes of a wave, result in every lane (as a wave-uniform value): the DPP reduction above and
+// one v_readlane per half -- no LDS round trips (a __shfl_xor butterfly is 12 ds_bpermute, each an LDS latency
+// on the serial path of the set-up kernel).
 __device__ __forceinline__ double wave_allsum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, wave_sum_to_last(v));
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, 63), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
 // Sum over the workgroup, result in every thread; fixed order (deterministic).
@@ -195,12 +201,13 @@ __device__ __forceinline__ double finalize_value(int mode, double sum, double nn
 }
 
 // 10^x as exp(x ln 10) with the product carried in two doubles (about 1 ulp, a fraction of the cost of pow()).
+__device__ __noinline__ double pow10_edge(double x) { return pow(10.0, x); }   // +-inf, NaN, over/underflow (10**-inf = 0)
 __device__ __forceinline__ double pow10_fast(double x) {
     constexpr double kLn10Hi = 2.302585092994045901, kLn10Lo = -2.1707562233822494e-16;
-    if (!(fabs(x) <= 300.0)) return pow(10.0, x);        // +-inf, NaN, over/underflow: the library's edge cases (10**-inf = 0)
+    if (!(fabs(x) <= 300.0)) return pow10_edge(x);       // the library's edge cases, kept out of line
     const double p = x * kLn10Hi;
     const double e = fma(x, kLn10Hi, -p) + x * kLn10Lo;
-    const double r = exp(p);
+    const double r = exp_neg(-p);                        // == exp(p) to the last bit (voigt_device.h), a third of the code
     return fma(r, e, r);
 }
 
@@ -214,12 +221,15 @@ __device__ inline void build_line_record(double* rec, double logN, double z, dou
                                          double dnu_seg) {
     const double cold = pow10_fast(logN);                // :357  10.0**N
     const double zp1 = z + 1.0;                          // :358
-    const double dnu = (b_kms * 1e5) / ln.wrest_cm;      // :360 with :376's b*1e5
-    const double a = ln.gamma / (4.0 * M_PI * dnu);      // :361
+    // ONE division per record: 1/dnu = wrest / b (:360 with :376's b*1e5); everything that the reference divides
+    // by dnu is a multiple of it (five IEEE divisions were a third of this kernel's serial path; the products
+    // differ from the quotients by an ulp, far below the 1e-11 cancellation noise u carries anyway)
+    const double rdnu = ln.wrest_cm / (b_kms * 1e5);
+    const double a = ln.gamma4pi * rdnu;                 // :361  gamma / (4 pi dnu)
     const double cne = kTauConst * cold * ln.f;          // :364
-    const double K = cne / dnu;                          // :365  tau = cne * H / dnu
-    rec[0] = zp1 / dnu;                                  // u = ((c/(lam/zp1)) - nujk)/dnu  (:362)
-    rec[1] = ln.nujk / dnu;
+    const double K = cne * rdnu;                         // :365  tau = cne * H / dnu
+    rec[0] = zp1 * rdnu;                                 // u = ((c/(lam/zp1)) - nujk)/dnu  (:362)
+    rec[1] = ln.nujk * rdnu;
     rec[2] = core_limit_x2(K);
     rec[3] = a;
     rec[4] = K;
@@ -233,7 +243,7 @@ __device__ inline void build_line_record(double* rec, double logN, double z, dou
     const float du2 = du * du, du4 = du2 * du2;
     const float q = (float)(kInterpC / kInterpTol) * (float)rec[5] * du4 * du4;
     double uthr = (double)__powf(fmaxf(q, 1.0f), 0.1f) * 1.02;                 // 2 % margin over the float estimate
-    uthr = fmax(uthr, sqrt(rec[2]) * 1.0000001);                              // never inside the core table's range
+    uthr = fmax(uthr, (double)__fsqrt_rn((float)rec[2]) * 1.000001);           // never inside the core table's range (x2c in [36, 64])
     rec[7] = !(uthr < 1e30) ? INFINITY : uthr;
     if (flag != 0.0) {
         // General-path line: the hot loop carries no test for it.  Its fast-path view is a line of zero
@@ -254,8 +264,10 @@ __device__ inline void build_line_record(double* rec, double logN, double z, dou
 __device__ unsigned long long g_stamps[8192 * 8];
 __device__ unsigned long long g_dbg[4];   // [0] interpolated segments, [1] segments seen
 #define MCALF_STAMP(k) do { if (threadIdx.x == 0 && w < 8192) g_stamps[w * 8 + (k)] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#define MCALF_STAMP_SLOT(k) do { if (threadIdx.x == 0 && w < 8192) g_stamps[w * 8 + (k)] = blockIdx.x; } while (0)
 #else
 #define MCALF_STAMP(k) do { } while (0)
+#define MCALF_STAMP_SLOT(k) do { } while (0)
 #endif
 
 // acc += a * b and acc += a with the accumulator tied to its register: without the tie the compiler
@@ -385,11 +397,81 @@ __device__ __forceinline__ double sample_param(const KArgs& a, const double* __r
     return v;
 }
 
+constexpr int kSetupBlockMax = 512;
+constexpr int kOrderBuckets = 64;       // component counts 0 .. 62 get a bucket each, larger ones share the last
+constexpr int kOrderKeys = 16;          // keys a thread of the ordering workgroup holds at a time
+
+// Active components of live point s: int(p[startind]) on the numpy path (:428), floor on the JAX path (:616),
+// clamped to [0, ncompmax].
 template <bool kZeroPad>
-__global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long batch) {
-    const long s = blockIdx.x;
+__device__ __forceinline__ int sample_ncomp(const KArgs& a, long s) {
+    const double ncv = sample_param(a, a.P + (size_t)s * a.ndim, a.startind);
+    const double nct = kZeroPad ? floor(ncv) : trunc(ncv);
+    return (nct >= 1.0) ? ((nct >= (double)a.ncompmax) ? a.ncompmax : (int)nct) : 0;
+}
+
+// One workgroup of the set-up kernel: counting sort of the live points by component count, most components
+// first, into a.order.  The fused kernel's queue then hands out similar work items next to each other (the two
+// workgroups that share a CU run evenly matched items: measured -2.4 % kernel time at config C with rows
+// sorted on the host) and the shortest items last.  LDS atomics only; the order inside a bucket is whatever the
+// atomics give, which changes who evaluates a live point, never its value.
+template <bool kZeroPad>
+__device__ void build_order(const KArgs& a, long batch) {
+    __shared__ int hist[kOrderBuckets];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (tid < kOrderBuckets) hist[tid] = 0;
+    __syncthreads();
+    const long chunk = (long)kOrderKeys * nthr;
+    auto load_keys = [&](long base, int (&key)[kOrderKeys]) {
+#pragma unroll
+        for (int k = 0; k < kOrderKeys; ++k) {                     // independent loads: one memory round trip per chunk
+            const long s = base + (long)k * nthr + tid;
+            key[k] = (s < batch) ? min(a.ncompmax - sample_ncomp<kZeroPad>(a, s), kOrderBuckets - 1) : -1;
+        }
+    };
+    int key[kOrderKeys];
+    // pass 1: bucket counts
+    for (long base = 0; base < batch; base += chunk) {
+        load_keys(base, key);
+#pragma unroll
+        for (int k = 0; k < kOrderKeys; ++k)
+            if (key[k] >= 0) atomicAdd(&hist[key[k]], 1);
+    }
+    __syncthreads();
+    // counts -> first position of each bucket: exclusive prefix sum over the 64 buckets by one wave
+    if (tid < 64) {
+        static_assert(kOrderBuckets == 64, "one bucket per lane");
+        const int c = hist[tid];
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (tid >= off) incl += up;
+        }
+        hist[tid] = incl - c;
+    }
+    __syncthreads();
+    // pass 2: positions.  A batch of one chunk (4096 live points with 256 threads) still holds its keys.
+    for (long base = 0; base < batch; base += chunk) {
+        if (batch > chunk) load_keys(base, key);
+#pragma unroll
+        for (int k = 0; k < kOrderKeys; ++k)
+            if (key[k] >= 0) a.order[atomicAdd(&hist[key[k]], 1)] = (int)(base + (long)k * nthr + tid);
+    }
+}
+
+template <bool kZeroPad>
+__global__ __launch_bounds__(kSetupBlockMax) void mcalf_sample_kernel(const KArgs a, long batch) {
+    // one WAVE per live point, blockDim.x / 64 live points per workgroup (the waves never synchronise); with an
+    // ordered hand-out workgroup 0 builds the order and the live points start at workgroup 1
+    int blk = blockIdx.x;
+    if (a.order) {
+        if (blk == 0) { build_order<kZeroPad>(a, batch); return; }
+        --blk;
+    }
+    const long s = (long)blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (s >= batch) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     if (s == 0 && lane == 0) *a.queue = 0u;          // item queue of the fused kernel that follows on the stream
     const int rowlen = (a.mode == kModeOneComp) ? 5 : a.ndim;
     const double* p = a.P + (size_t)s * rowlen;
@@ -424,7 +506,11 @@ __global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long ba
     const int nTargetSlots = (a.mode == kModeOneComp) ? nl_eff : a.ncompmax * a.nlines;
     const int nSlots = nTargetSlots + ((a.mode == kModeOneComp) ? 0 : a.nfill);
     int ngenLane = 0;
+#if defined(MCALF_ABL_SETUP) && (MCALF_ABL_SETUP & 2)   // ablation builds only (tools/): no records
+    for (int slot = lane; slot < 0; slot += 64) {
+#else
     for (int slot = lane; slot < nSlots; slot += 64) {
+#endif
         double logN, z, b;
         const LineDev* ln;
         int dst;                                    // index in the compacted record list, -1: inactive
@@ -449,7 +535,7 @@ __global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long ba
         }
         double rec[kRecStride];
         build_line_record(rec, logN, z, b, *ln, a.dnu_seg);
-        if (dst >= 0 && rec[6] != 0.0) ++ngenLane;
+        ngenLane += __popcll(__ballot(dst >= 0 && rec[6] != 0.0));        // (wave-uniform count)
         if (dst >= 0) {
 #pragma unroll
             for (int k = 0; k < kRecStride; ++k) recs[dst * kRecStride + k] = rec[k];
@@ -476,28 +562,41 @@ __global__ __launch_bounds__(64) void mcalf_sample_kernel(const KArgs a, long ba
     const double inv2s2 = kZeroPad ? 1.0 / (2.0 * sigma * sigma) : 0.5 / (sigma * sigma);
     const double amp = kZeroPad ? 1.0 : 1.0 / (sqrt(2.0 * M_PI) * sigma);          // Gaussian1DKernel amplitude
     double wsum = 0.0;
+#if defined(MCALF_ABL_SETUP) && (MCALF_ABL_SETUP & 1)   // ablation builds only (tools/): no taps
+    if (false) {
+#else
     if (ntap8 <= 64) {                               // the usual case: one tap per lane, one exp
+#endif
         const double dk = (double)(lane - n);
-        const double g = (lane > 2 * n) ? 0.0 : ((n == 0 && !kZeroPad) ? 1.0 : exp(-(dk * dk) * inv2s2) * amp);
+        const double g = (lane > 2 * n) ? 0.0 : ((n == 0 && !kZeroPad) ? 1.0 : exp_neg((dk * dk) * inv2s2) * amp);
         const double gsum = wave_allsum(g);
         wsum = g / gsum;
         if (lane < ntap8 && writeTaps) taps[lane] = wsum;
-    } else {
+    } else
+#if defined(MCALF_ABL_SETUP) && (MCALF_ABL_SETUP & 1)
+    if (false)
+#endif
+    {
         double gsum = 0.0;
         for (int k = lane; k <= 2 * n; k += 64) {
             const double dk = (double)(k - n);
-            gsum += exp(-(dk * dk) * inv2s2) * amp;                                  // :669 / Gaussian1D
+            gsum += exp_neg((dk * dk) * inv2s2) * amp;                                  // :669 / Gaussian1D
         }
         gsum = wave_allsum(gsum);
         for (int k = lane; k < ntap8; k += 64) {
             const double dk = (double)(k - n);
-            const double w = (k <= 2 * n) ? exp(-(dk * dk) * inv2s2) * amp / gsum : 0.0;   // zero-padded to 8
+            const double w = (k <= 2 * n) ? exp_neg((dk * dk) * inv2s2) * amp / gsum : 0.0;   // zero-padded to 8
             wsum += w;
             if (writeTaps) taps[k] = w;
         }
     }
+#if defined(MCALF_ABL_SETUP) && (MCALF_ABL_SETUP & 1)
+    const double bot = 1.0;
+    const int ngen = 0;
+#else
     const double bot = kZeroPad ? 1.0 : wave_allsum(wsum);
-    const int ngen = (int)wave_allsum((double)ngenLane);
+    const int ngen = ngenLane;
+#endif
     if (lane == 0) {
         SampleHdr h;
         h.cont = cont; h.bot = bot; h.ncl = ncl; h.n = n; h.bad = bad ? 1 : 0; h.ngeneral = ngen;
@@ -613,7 +712,10 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     const int recTotal = a.ncl_cap * kRecStride, tapTotal = 2 * a.n_cap + 8;
     const int nItems = a.nitems;
 
-    int w = blockIdx.x;                                // grid <= nItems
+    // ticket -> work item: with an ordered hand-out, ticket t is tile (t % ntiles) of live point order[t / ntiles]
+    constexpr bool kOrdered = kSelfHalo;               // (the host passes a.order only to these instantiations)
+    auto item_of = [&](int t) -> int { return (kOrdered && a.order) ? a.order[t] : t; };
+    int w = item_of(blockIdx.x);                       // grid <= nItems
     ItemLoads L;
     request_item<kZeroPad, kSelfHalo>(a, w, tid0, L);
 
@@ -685,13 +787,26 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             if (idx < VT_NY * VT_NTOT) sT[idx] = L.treg[i];
         }
         // the item after this one: the first comes from the grid, the rest from the queue
-        if (tid == 0) *sNext = a.persist ? (int)gridDim.x + (int)atomicAdd(a.queue, 1u) : nItems;
+        // Ticket of the item after this one: the first comes from the grid, the rest from the queue.  With an
+        // ordered hand-out (single-tile instantiations) the ticket still has to be looked up in a.order -- a second
+        // dependent memory round trip -- so thread 0 keeps both in registers and publishes them behind the
+        // component loop, where they have long arrived; otherwise the ticket is published at once.
+        int tHeld = nItems, wHeld = 0;
+        if (tid == 0) {
+            tHeld = a.persist ? (int)gridDim.x + (int)atomicAdd(a.queue, 1u) : nItems;
+            if (kOrdered) wHeld = (tHeld < nItems) ? item_of(tHeld) : 0;
+            else { sNext[0] = tHeld; sNext[1] = tHeld; }
+        }
 
         MCALF_STAMP(1);
         // ---- 2. tau for this thread's pixels ----------------------------------------------------
         const int shift = a.n_cap - n;
         __syncthreads();                                   // publishes sRec, sW, sT, sNext
-        const int wNext = __builtin_amdgcn_readfirstlane(*sNext);
+        int tNext = 0, wNext = 0;
+        if (!kOrdered) {
+            tNext = __builtin_amdgcn_readfirstlane(sNext[0]);            // the next ticket ...
+            wNext = __builtin_amdgcn_readfirstlane(sNext[1]);            // ... and the work item it stands for
+        }
         MCALF_STAMP(2);
         int buf = 0;
 #ifdef MCALF_ABL_NOLOOP   // ablation builds only (tools/); never defined in the product build
@@ -813,8 +928,17 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::: "memory");
         }
-        if (tid < kTileSlack) sF[tile_pos(extTight + tid)] = 0.0;
+        if (tid < kTileSlack) {
+            double zero = 0.0;
+            asm volatile("" : "+v"(zero));                 // formed here: hoisted out of the item loop it was spilled
+            sF[tile_pos(extTight + tid)] = zero;
+        }
+        if (kOrdered && tid == 0) { sNext[0] = tHeld; sNext[1] = wHeld; }
         __syncthreads();
+        if (kOrdered) {
+            tNext = __builtin_amdgcn_readfirstlane(sNext[0]);
+            wNext = __builtin_amdgcn_readfirstlane(sNext[1]);
+        }
 
         MCALF_STAMP(4);
         // ---- 3+4. convolution, continuum, likelihood terms -------------------------------------
@@ -906,7 +1030,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
                 }
             }
         }
-        const bool more = wNext < nItems;
+        const bool more = tNext < nItems;
         MCALF_STAMP(5);
         // The next item's global loads go out here (the pixel data of this item are consumed, so the registers
         // are free): they land while the reduction and the barrier that ends the item run.
@@ -936,7 +1060,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             // LSF wider than the provisioned halo: the model was not computed (the reference would build a longer
             // kernel); the row must not look like a valid likelihood -> logL = -inf, chi2 = +inf
             if (bad) { ssum = INFINITY; scnt = 1.0; }
-            MCALF_STAMP(6);
+            MCALF_STAMP_SLOT(6);                         // (diagnostic builds: which workgroup slot ran the item)
             MCALF_STAMP(7);
             if (a.ntiles == 1) {
                 a.out[s] = finalize_value(a.mode, ssum, scnt, a.asymm != 0, t4, t5, a.veto4, a.veto5);
@@ -992,6 +1116,8 @@ __global__ void mcalf_scale_cube_kernel(const double* lo, const double* hi, cons
 // ==========================================================================================
 using namespace mcalf;
 
+#define MCALF_STR_(x) #x
+#define MCALF_STR(x) MCALF_STR_(x)
 static thread_local std::string g_last_error;
 constexpr int kMaxChunks = 8;
 
@@ -1040,15 +1166,28 @@ struct mcalf_ctx {
     int host_plan_n = 0;                       // host-pointer entry (0 = the built-in plans)
     int num_cu = 256;
     int persist = 1;                    // fused kernel as a persistent grid (MCALF_PERSIST=0: one workgroup per item)
+    int setup_block = 512;              // threads per workgroup of the set-up kernel (MCALF_SETUP_BLOCK: 64 .. 512)
     unsigned int* d_queue = nullptr;    // [kMaxChunks] work-item queues of the persistent kernel
+    int* d_order = nullptr;             // [batch] hand-out order of the persistent kernel (per row block)
+    size_t cap_order = 0;
+    int ordered = 1;                    // MCALF_ORDER=0: hand the live points out in row order
     hipStream_t aux[kMaxChunks - 1] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxChunks - 1] = {};
     // multi-GPU: the communicator of mcalf_comm_init (one process per GPU, RCCL over xGMI)
     ncclComm_t comm = nullptr;
     int comm_ranks = 0, comm_rank = -1;
+    hipStream_t comm_stream = nullptr;      // the exchange runs here, behind an event of the launch stream
+    hipEvent_t ev_kernels = nullptr;        // launch stream -> comm stream: this step's logL block is complete
+    hipEvent_t ev_comm[2] = {};             // comm stream -> launch stream: exchange of call k (slot k & 1) has landed
+    bool ev_comm_used[2] = {};
+    unsigned comm_calls = 0;
+    int comm_overlap = 0;                   // 0: every gather call ends with the launch stream waiting for its exchange
+    bool comm_dead = false;                 // aborted after a failure inside an exchange
+    bool fail_preflight = false;            // MCALF_TEST_FAIL_PREFLIGHT=1: tests inject a workspace-growth failure
     // page-locked staging of the host-pointer entries: parameter rows in, scalars out
     double* h_stage = nullptr;
     size_t cap_stage = 0;
+    mcalf_launch_info_t last = {};      // what the last call did (mcalf_last_launch)
 };
 
 static int set_err(mcalf_ctx* ctx, int code, const char* fmt, ...) {
@@ -1107,7 +1246,10 @@ static int upload_tables(mcalf_ctx* ctx, double** d_tabs) {
     return MCALF_OK;
 }
 
-extern "C" const char* mcalf_version(void) { return "mcalf_hip 0.1 (gfx950, abi 1)"; }
+#ifndef MCALF_SRC_HASH
+#define MCALF_SRC_HASH "unstamped"      // mc-alf_amd/build.py passes the sha256 of the kernel sources
+#endif
+extern "C" const char* mcalf_version(void) { return "mcalf_hip 0.3 (gfx950, abi " MCALF_STR(MCALF_ABI_VERSION) ") src " MCALF_SRC_HASH; }
 
 extern "C" const char* mcalf_last_error(const mcalf_ctx* ctx) {
     return ctx ? ctx->err.c_str() : g_last_error.c_str();
@@ -1121,7 +1263,7 @@ extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     comm_release(ctx);
     void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_err, ctx->d_tabs, ctx->d_lines, ctx->d_wtab, ctx->d_segok,
                     ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds, ctx->d_prior, ctx->d_recs, ctx->d_taps, ctx->d_hdr,
-                    ctx->d_queue};
+                    ctx->d_queue, ctx->d_order};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
@@ -1132,6 +1274,10 @@ extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
         if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : ctx->aux)
         if (st) (void)hipStreamDestroy(st);
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
+    if (ctx->ev_kernels) (void)hipEventDestroy(ctx->ev_kernels);
+    for (hipEvent_t e : ctx->ev_comm)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1278,7 +1424,7 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         const mcalf_line& src = (l < ctx->nlines) ? sp->lines[l] : sp->fill;
         lines[l].wrest_cm = src.wrest_A / 1e8;             // :376
         lines[l].f = src.f;
-        lines[l].gamma = src.gamma;
+        lines[l].gamma4pi = src.gamma / (4.0 * M_PI);      // :361
         lines[l].nujk = kCcgs / lines[l].wrest_cm;         // :359
     }
     const size_t nb = (size_t)ctx->npix * sizeof(double);
@@ -1361,6 +1507,11 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         HIP_TRY(ctx, hipMemset(ctx->d_queue, 0, kMaxChunks * sizeof(unsigned int)));
         const char* pe = std::getenv("MCALF_PERSIST");
         if (pe && *pe) ctx->persist = std::atoi(pe) != 0;
+        if (const char* oe = std::getenv("MCALF_ORDER")) ctx->ordered = std::atoi(oe) != 0;
+        if (const char* sb = std::getenv("MCALF_SETUP_BLOCK")) {      // diagnostic: geometry of the set-up kernel
+            const int v = std::atoi(sb);
+            if (v >= 64 && v <= kSetupBlockMax && v % 64 == 0) ctx->setup_block = v;
+        }
         if (const char* hp = std::getenv("MCALF_HOST_PLAN")) {      // e.g. "1,3,4": relative block sizes (diagnostic)
             int n = 0;
             for (const char* q = hp; *q && n < kMaxChunks;) {
@@ -1371,6 +1522,7 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
             }
             if (n > 0) ctx->host_plan_n = n;
         }
+        if (const char* fp = std::getenv("MCALF_TEST_FAIL_PREFLIGHT")) ctx->fail_preflight = std::atoi(fp) != 0;
         const char* env = std::getenv("MCALF_CHUNKS");            // 0 / unset: automatic; n: exactly n row blocks
         if (env && *env) {
             const int v = std::atoi(env);
@@ -1411,11 +1563,18 @@ extern "C" int mcalf_info(const mcalf_ctx* ctx, mcalf_info_t* info) {
     return MCALF_OK;
 }
 
+extern "C" int mcalf_last_launch(const mcalf_ctx* ctx, mcalf_launch_info_t* info) {
+    if (!ctx || !info) return set_err(nullptr, MCALF_ERR_INVALID, "NULL argument");
+    *info = ctx->last;
+    return MCALF_OK;
+}
+
 static int grow_sample_ws(mcalf_ctx* ctx, int64_t batch) {
     int rc;
     if ((rc = grow(ctx, &ctx->d_recs, &ctx->cap_recs, (size_t)batch * ctx->ncl_cap * kRecStride))) return rc;
     if ((rc = grow(ctx, &ctx->d_taps, &ctx->cap_taps, (size_t)batch * (2 * (size_t)ctx->n_cap + 8)))) return rc;
     if ((rc = grow(ctx, &ctx->d_hdr, &ctx->cap_hdr, (size_t)batch))) return rc;
+    if ((rc = grow(ctx, &ctx->d_order, &ctx->cap_order, (size_t)batch))) return rc;
     return MCALF_OK;
 }
 
@@ -1474,11 +1633,16 @@ static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0
     const int64_t slots = 2LL * ctx->num_cu;
     a.persist = (ctx->persist && a.nitems >= 4 * slots) ? 1 : 0;
     a.queue = ctx->d_queue + chunk;
+    a.order = (a.persist && ctx->ordered && ctx->selfhalo && mode != kModeOneComp) ? ctx->d_order + row0 : nullptr;
     const dim3 grid((unsigned)(a.persist ? slots : a.nitems)), block(kBlock);
+    ctx->last.persistent = a.persist; ctx->last.grid = (int32_t)grid.x; ctx->last.items = a.nitems;
+    ctx->last.lines_per_sync = ctx->lps; ctx->last.selfhalo = ctx->selfhalo;
+    const int per_wg = ctx->setup_block / 64;                 // live points per set-up workgroup (one wave each)
+    const dim3 sgrid((unsigned)((nrows + per_wg - 1) / per_wg) + (a.order ? 1u : 0u)), sblock((unsigned)ctx->setup_block);
     if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX)
-        hipLaunchKernelGGL(mcalf_sample_kernel<true>, dim3((unsigned)nrows), dim3(64), 0, stream, a, (long)nrows);
+        hipLaunchKernelGGL(mcalf_sample_kernel<true>, sgrid, sblock, 0, stream, a, (long)nrows);
     else
-        hipLaunchKernelGGL(mcalf_sample_kernel<false>, dim3((unsigned)nrows), dim3(64), 0, stream, a, (long)nrows);
+        hipLaunchKernelGGL(mcalf_sample_kernel<false>, sgrid, sblock, 0, stream, a, (long)nrows);
     HIP_TRY(ctx, hipGetLastError());
     const bool timed = timed_ok && ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used], stream));
@@ -1527,18 +1691,29 @@ static int64_t chunk_begin(int64_t batch, int nchunks, int c) { return batch * c
 // Enqueue one batch on `stream` (asynchronous).  With several row blocks, blocks 1.. go to the context's
 // auxiliary streams between a fork event recorded on `stream` and join events `stream` waits for, so the call
 // keeps plain stream semantics for the caller (and can be captured into a hipGraph).
-static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill,
-                  double* d_out, double* d_model, hipStream_t stream, bool from_cube = false,
-                  double* d_theta = nullptr) {
+// Everything of a launch that can fail WITHOUT anything having been enqueued: the range check and the growth of
+// the per-sample workspaces (hipMalloc).  The collective entry runs it before it enqueues anything, so that a rank
+// that fails here can still take its part in the exchange (mcalf_loglike_gatherv_device).
+static int launch_preflight(mcalf_ctx* ctx, int mode, int64_t batch) {
     if (batch == 0) return MCALF_OK;
     if (batch < 0 || batch * (int64_t)ctx->ntiles > 0x7fff0000LL)
         return set_err(ctx, MCALF_ERR_RANGE, "batch %lld too large", (long long)batch);
     const bool reduces = (mode == kModeLogL || mode == kModeChi2);
     int rc;
+    if (ctx->fail_preflight) return set_err(ctx, MCALF_ERR_NOMEM, "workspace growth failed (injected by MCALF_TEST_FAIL_PREFLIGHT)");
     if (reduces && ctx->ntiles > 1 && (rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4)))
         return rc;
-    if ((rc = grow_sample_ws(ctx, batch))) return rc;
+    return grow_sample_ws(ctx, batch);
+}
+
+static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill,
+                  double* d_out, double* d_model, hipStream_t stream, bool from_cube = false,
+                  double* d_theta = nullptr) {
+    if (batch == 0) return MCALF_OK;
+    int rc;
+    if ((rc = launch_preflight(ctx, mode, batch))) return rc;
     const int nchunks = ctx->profiling ? 1 : pick_chunks(ctx, batch);
+    ctx->last.row_blocks = nchunks;
     if (nchunks == 1)
         return launch_range(ctx, mode, dP, 0, batch, 0, targonly, onecomp_fill, d_out, d_model, stream, from_cube,
                             d_theta, true);
@@ -1602,6 +1777,7 @@ extern "C" int mcalf_loglike_batch_device(mcalf_ctx* ctx, const double* dP, int6
                                           void* stream) {
     if (!ctx || (batch > 0 && (!dP || !dlogL))) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->last.path = MCALF_PATH_DEVICE; ctx->last.pinned_in = ctx->last.pinned_out = 0;
     return launch(ctx, kModeLogL, dP, batch, 0, 0, dlogL, nullptr, (hipStream_t)stream);
 }
 
@@ -1609,6 +1785,7 @@ extern "C" int mcalf_model_batch_device(mcalf_ctx* ctx, const double* dP, int64_
                                         double* dflux, void* stream) {
     if (!ctx || (batch > 0 && (!dP || !dflux))) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->last.path = MCALF_PATH_DEVICE; ctx->last.pinned_in = ctx->last.pinned_out = 0;
     return launch(ctx, kModeModel, dP, batch, targonly ? 1 : 0, 0, nullptr, dflux, (hipStream_t)stream);
 }
 
@@ -1682,8 +1859,16 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
         (void)hipGetLastError();
         d_stage_out = nullptr;                            // (caller's page-locked memory that is not device-mapped)
     }
+    ctx->last.path = MCALF_PATH_HOST_PIPELINED; ctx->last.row_blocks = nchunks;
+    ctx->last.pinned_in = pin_in ? 1 : 0; ctx->last.pinned_out = pin_out ? 1 : 0;
     hipStream_t streams[2] = {ctx->stream, ctx->aux[0]};
-    for (int c = 0; c < nchunks; ++c) {
+    // A failure in block k leaves blocks < k in flight on both streams, reading the staging block / the caller's
+    // page-locked rows and writing the caller's results: never return under them (the next call may free the
+    // staging block, the caller its arrays).  Every error below therefore leaves through `fail`.
+    hipError_t he = hipSuccess;
+    const char* what = "";
+    rc = MCALF_OK;
+    for (int c = 0; c < nchunks && rc == MCALF_OK && he == hipSuccess; ++c) {
         const int64_t r0 = bounds[c], n = bounds[c + 1] - r0;
         if (n == 0) continue;
         hipStream_t st = streams[c & 1];
@@ -1692,16 +1877,22 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
             std::memcpy(stage_in + (size_t)r0 * rowlen, src, (size_t)n * rowlen * sizeof(double));
             src = stage_in + (size_t)r0 * rowlen;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_P + (size_t)r0 * rowlen, src, (size_t)n * rowlen * sizeof(double),
-                                    hipMemcpyHostToDevice, st));
-        if ((rc = launch_range(ctx, mode, ctx->d_P, r0, n, c, targonly, fill, d_stage_out ? d_stage_out : ctx->d_out, nullptr,
-                               st, false, nullptr, nchunks == 1)))
-            return rc;
-        if (!d_stage_out)
-            HIP_TRY(ctx, hipMemcpyAsync(stage_out + r0, ctx->d_out + r0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+        he = hipMemcpyAsync(ctx->d_P + (size_t)r0 * rowlen, src, (size_t)n * rowlen * sizeof(double), hipMemcpyHostToDevice, st);
+        if (he != hipSuccess) { what = "H2D copy of a row block"; break; }
+        rc = launch_range(ctx, mode, ctx->d_P, r0, n, c, targonly, fill, d_stage_out ? d_stage_out : ctx->d_out, nullptr, st,
+                          false, nullptr, nchunks == 1);
+        if (rc != MCALF_OK) break;
+        if (!d_stage_out) {
+            he = hipMemcpyAsync(stage_out + r0, ctx->d_out + r0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
+            if (he != hipSuccess) { what = "D2H copy of a result block"; break; }
+        }
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (nchunks > 1) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux[0]));
+    const hipError_t s0 = hipStreamSynchronize(ctx->stream);
+    const hipError_t s1 = (nchunks > 1) ? hipStreamSynchronize(ctx->aux[0]) : hipSuccess;
+    if (rc != MCALF_OK) return rc;                                   // (message set by launch_range)
+    if (he != hipSuccess) return set_err(ctx, MCALF_ERR_HIP, "%s failed: %s", what, hipGetErrorString(he));
+    if (s0 != hipSuccess || s1 != hipSuccess)
+        return set_err(ctx, MCALF_ERR_HIP, "stream synchronisation failed: %s", hipGetErrorString(s0 != hipSuccess ? s0 : s1));
     if (!pin_out) std::memcpy(out_scalar, stage_out, (size_t)batch * sizeof(double));
     return MCALF_OK;
 }
@@ -1722,6 +1913,7 @@ static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
             HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->d_small, ctx->h_small, 0));
         }
         std::memcpy(ctx->h_small, P, (size_t)batch * rowlen * sizeof(double));
+        ctx->last.path = MCALF_PATH_HOST_ZEROCOPY; ctx->last.pinned_in = ctx->last.pinned_out = 0;
         rc = launch(ctx, mode, ctx->d_small, batch, targonly, fill, ctx->d_small + kSmallDoubles, nullptr, ctx->stream);
         if (rc) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1732,6 +1924,7 @@ static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
     if (out_scalar && (rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
     if (out_model && (rc = grow(ctx, &ctx->d_model, &ctx->cap_model, (size_t)batch * ctx->npix))) return rc;
     if (out_scalar && !out_model) return run_host_pipelined(ctx, mode, P, batch, rowlen, targonly, fill, out_scalar);
+    ctx->last.path = MCALF_PATH_HOST_STAGED; ctx->last.pinned_in = ctx->last.pinned_out = 0;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_P, P, (size_t)batch * rowlen * sizeof(double), hipMemcpyHostToDevice,
                                 ctx->stream));
     rc = launch(ctx, mode, ctx->d_P, batch, targonly, fill, out_scalar ? ctx->d_out : nullptr,
@@ -1779,6 +1972,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -1792,8 +1986,14 @@ int rccl_load(mcalf_ctx* ctx) {
     if (g_rccl.ok) return MCALF_OK;
     const char* names[] = {"librccl.so.1", "librccl.so"};
     void* h = nullptr;
-    for (const char* n : names)                           // a copy already in the process (torch's) wins
-        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+    // MCALF_RCCL_LIB: an explicit library (tests put a two-process stand-in here to drive the N > 1 branch on a
+    // one-GPU box; see tests/stubs/)
+    if (const char* over = std::getenv("MCALF_RCCL_LIB")) {
+        if (*over && !(h = dlopen(over, RTLD_NOW | RTLD_LOCAL)))
+            return set_err(ctx, MCALF_ERR_COMM, "MCALF_RCCL_LIB=%s: %s", over, dlerror());
+    }
+    for (int i = 0; !h && i < 2; ++i)                    // a copy already in the process (torch's) wins
+        h = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     for (int i = 0; !h && i < 2; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
     if (!h) return set_err(ctx, MCALF_ERR_COMM, "librccl.so not found: %s", dlerror());
     g_rccl.handle = h;
@@ -1803,6 +2003,7 @@ int rccl_load(mcalf_ctx* ctx) {
     MCALF_SYM(GetUniqueId, "ncclGetUniqueId")
     MCALF_SYM(CommInitRank, "ncclCommInitRank")
     MCALF_SYM(CommDestroy, "ncclCommDestroy")
+    MCALF_SYM(CommAbort, "ncclCommAbort")
     MCALF_SYM(Send, "ncclSend")
     MCALF_SYM(Recv, "ncclRecv")
     MCALF_SYM(GroupStart, "ncclGroupStart")
@@ -1822,10 +2023,27 @@ int rccl_load(mcalf_ctx* ctx) {
     } while (0)
 
 static void comm_release(mcalf_ctx* ctx) {
-    if (ctx->comm && g_rccl.ok) (void)g_rccl.CommDestroy(ctx->comm);
+    if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+    if (ctx->comm && g_rccl.ok) (void)(ctx->comm_dead ? g_rccl.CommAbort(ctx->comm) : g_rccl.CommDestroy(ctx->comm));
     ctx->comm = nullptr;
     ctx->comm_ranks = 0;
     ctx->comm_rank = -1;
+    ctx->comm_dead = false;
+    ctx->comm_calls = 0;
+    ctx->ev_comm_used[0] = ctx->ev_comm_used[1] = false;
+}
+
+// A failure inside an exchange leaves the ranks out of step: the communicator is aborted (outstanding RCCL work
+// is torn down instead of waiting for peers that will never call) and every later gather on it is refused.
+static int comm_fail(mcalf_ctx* ctx, const char* what, ncclResult_t r) {
+    const int rc = set_err(ctx, MCALF_ERR_COMM, "%s failed: %s; the communicator has been aborted -- call mcalf_comm_destroy / "
+                           "mcalf_comm_init on every rank before the next gather", what, g_rccl.GetErrorString(r));
+    if (ctx->comm && !ctx->comm_dead) {
+        (void)g_rccl.CommAbort(ctx->comm);
+        ctx->comm = nullptr;
+    }
+    ctx->comm_dead = true;
+    return rc;
 }
 
 extern "C" int mcalf_comm_unique_id(void* id128) {
@@ -1868,38 +2086,118 @@ extern "C" int mcalf_comm_destroy(mcalf_ctx* ctx) {
     return MCALF_OK;
 }
 
-extern "C" int mcalf_loglike_gather_device(mcalf_ctx* ctx, const double* dP, int64_t batch_local, double* dlogL_local,
-                                           double* dlogL_all, int32_t root, void* stream) {
+extern "C" int mcalf_comm_set_overlap(mcalf_ctx* ctx, int32_t on) {
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    ctx->comm_overlap = on ? 1 : 0;
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_comm_join(mcalf_ctx* ctx, void* stream) {
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int k = 0; k < 2; ++k)
+        if (ctx->ev_comm_used[k]) HIP_TRY(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_comm[k], 0));
+    return MCALF_OK;
+}
+
+static int comm_ensure_streams(mcalf_ctx* ctx) {
+    if (!ctx->comm_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    if (!ctx->ev_kernels) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_kernels, hipEventDisableTiming));
+    for (hipEvent_t& e : ctx->ev_comm)
+        if (!e) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_loglike_gatherv_device(mcalf_ctx* ctx, const double* dP, int64_t batch_local, double* dlogL_local,
+                                            double* dlogL_all, const int64_t* counts, int32_t root, void* stream) {
+    // ---- 1. argument checks: a non-zero return from here means NOTHING was enqueued on this rank ----------
     if (!ctx || batch_local < 0 || (batch_local > 0 && (!dP || !dlogL_local)))
         return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    if (ctx->comm_dead) return set_err(ctx, MCALF_ERR_COMM, "the communicator was aborted after a failed exchange; re-initialise it");
     if (!ctx->comm) return set_err(ctx, MCALF_ERR_INVALID, "mcalf_comm_init has not been called");
-    if (root < 0 || root >= ctx->comm_ranks) return set_err(ctx, MCALF_ERR_INVALID, "root %d out of range", root);
-    const bool is_root = ctx->comm_rank == root;
-    if (is_root && batch_local > 0 && !dlogL_all) return set_err(ctx, MCALF_ERR_INVALID, "root needs dlogL_all");
+    const int nranks = ctx->comm_ranks, me = ctx->comm_rank;
+    if (root < 0 || root >= nranks) return set_err(ctx, MCALF_ERR_INVALID, "root %d out of range", root);
+    if (counts && counts[me] != batch_local)
+        return set_err(ctx, MCALF_ERR_INVALID, "counts[%d] = %lld but batch_local = %lld", me, (long long)counts[me],
+                       (long long)batch_local);
+    const bool is_root = me == root;
+    int64_t total = 0, my_off = 0;
+    for (int r = 0; r < nranks; ++r) {
+        const int64_t c = counts ? counts[r] : batch_local;
+        if (c < 0) return set_err(ctx, MCALF_ERR_INVALID, "counts[%d] is negative", r);
+        if (r < me) my_off += c;
+        total += c;
+    }
+    if (is_root && total > 0 && !dlogL_all) return set_err(ctx, MCALF_ERR_INVALID, "root needs dlogL_all");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch(ctx, kModeLogL, dP, batch_local, 0, 0, dlogL_local, nullptr, st);
-    if (rc) return rc;
-    if (batch_local == 0) return MCALF_OK;
     const size_t n = (size_t)batch_local;
-    if (is_root) {
-        HIP_TRY(ctx, hipMemcpyAsync(dlogL_all + (size_t)root * n, dlogL_local, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-        if (ctx->comm_ranks > 1) {
-            RCCL_TRY(ctx, g_rccl.GroupStart());
-            for (int r = 0; r < ctx->comm_ranks; ++r) {
-                if (r == root) continue;
-                ncclResult_t e = g_rccl.Recv(dlogL_all + (size_t)r * n, n, ncclFloat64, r, ctx->comm, st);
-                if (e != ncclSuccess) {
-                    (void)g_rccl.GroupEnd();
-                    return set_err(ctx, MCALF_ERR_COMM, "ncclRecv from rank %d failed: %s", r, g_rccl.GetErrorString(e));
-                }
-            }
-            RCCL_TRY(ctx, g_rccl.GroupEnd());
-        }
-    } else {
-        RCCL_TRY(ctx, g_rccl.Send(dlogL_local, n, ncclFloat64, root, ctx->comm, st));
+    ctx->last.path = MCALF_PATH_DEVICE; ctx->last.pinned_in = ctx->last.pinned_out = 0;
+
+    // ---- 2. everything that can fail locally, BEFORE anything is enqueued ---------------------------------
+    // A rank that fails here (or in the kernel launches below) still takes its part in the exchange, with a block
+    // of NaNs, and reports its error afterwards: the peers' sends / receives complete and the root sees which rows
+    // are missing, instead of waiting in ncclRecv for a send that never comes.
+    int rc_local = launch_preflight(ctx, kModeLogL, batch_local);
+    if (nranks > 1 || ctx->comm_overlap) {
+        const int rs = comm_ensure_streams(ctx);
+        if (rs != MCALF_OK) return comm_fail(ctx, "creating the exchange stream / events", ncclSystemError);
     }
-    return MCALF_OK;
+    const unsigned slot = ctx->comm_calls & 1u;
+    // the exchange that used this slot two calls ago read the caller's buffers of that call: it must have
+    // landed before this call's kernels overwrite them (a caller in overlap mode alternates two buffer pairs)
+    if (ctx->ev_comm_used[slot]) {
+        if (hipStreamWaitEvent(st, ctx->ev_comm[slot], 0) != hipSuccess)
+            return comm_fail(ctx, "hipStreamWaitEvent", ncclSystemError);
+    }
+    // ---- 3. kernels ------------------------------------------------------------------------------------------
+    if (rc_local == MCALF_OK && n > 0) rc_local = launch(ctx, kModeLogL, dP, batch_local, 0, 0, dlogL_local, nullptr, st);
+    const std::string local_msg = ctx->err;
+    if (rc_local != MCALF_OK && n > 0) (void)hipMemsetAsync(dlogL_local, 0xFF, n * sizeof(double), st);   // NaN block
+    // ---- 4. exchange -----------------------------------------------------------------------------------------
+    if (nranks == 1 && !ctx->comm_overlap) {
+        // one rank: the "gather" is a device-to-device copy behind the kernels
+        if (n > 0 && hipMemcpyAsync(dlogL_all, dlogL_local, n * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return comm_fail(ctx, "hipMemcpyAsync", ncclSystemError);
+    } else {
+        hipStream_t cs = ctx->comm_stream;
+        if (hipEventRecord(ctx->ev_kernels, st) != hipSuccess || hipStreamWaitEvent(cs, ctx->ev_kernels, 0) != hipSuccess)
+            return comm_fail(ctx, "hipEventRecord / hipStreamWaitEvent", ncclSystemError);
+        if (is_root) {
+            if (n > 0 && hipMemcpyAsync(dlogL_all + my_off, dlogL_local, n * sizeof(double), hipMemcpyDeviceToDevice, cs) != hipSuccess)
+                return comm_fail(ctx, "hipMemcpyAsync", ncclSystemError);
+            if (nranks > 1) {
+                ncclResult_t e = g_rccl.GroupStart();
+                int64_t off = 0;
+                for (int r = 0; r < nranks && e == ncclSuccess; ++r) {
+                    const int64_t c = counts ? counts[r] : batch_local;
+                    if (r != root && c > 0) e = g_rccl.Recv(dlogL_all + off, (size_t)c, ncclFloat64, r, ctx->comm, cs);
+                    off += c;
+                }
+                const ncclResult_t e2 = g_rccl.GroupEnd();
+                if (e != ncclSuccess || e2 != ncclSuccess) return comm_fail(ctx, "ncclRecv group", e != ncclSuccess ? e : e2);
+            }
+        } else if (n > 0) {
+            const ncclResult_t e = g_rccl.Send(dlogL_local, n, ncclFloat64, root, ctx->comm, cs);
+            if (e != ncclSuccess) return comm_fail(ctx, "ncclSend", e);
+        }
+        if (hipEventRecord(ctx->ev_comm[slot], cs) != hipSuccess) return comm_fail(ctx, "hipEventRecord", ncclSystemError);
+        ctx->ev_comm_used[slot] = true;
+        // default: plain stream semantics -- whatever follows on `stream` sees the gathered vector
+        if (!ctx->comm_overlap && hipStreamWaitEvent(st, ctx->ev_comm[slot], 0) != hipSuccess)
+            return comm_fail(ctx, "hipStreamWaitEvent", ncclSystemError);
+    }
+    ctx->comm_calls++;
+    if (rc_local != MCALF_OK) {
+        ctx->err = local_msg + " (this rank sent a block of NaNs so that the exchange completes)";
+        g_last_error = ctx->err;
+    }
+    return rc_local;
+}
+
+extern "C" int mcalf_loglike_gather_device(mcalf_ctx* ctx, const double* dP, int64_t batch_local, double* dlogL_local,
+                                           double* dlogL_all, int32_t root, void* stream) {
+    return mcalf_loglike_gatherv_device(ctx, dP, batch_local, dlogL_local, dlogL_all, nullptr, root, stream);
 }
 
 extern "C" int mcalf_set_prior(mcalf_ctx* ctx, const double* lo, const double* hi, int32_t int_ncomp) {
@@ -1922,6 +2220,7 @@ extern "C" int mcalf_loglike_cube_batch_device(mcalf_ctx* ctx, const double* dcu
     if (!ctx || (batch > 0 && (!dcube || !dlogL))) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
     if (!ctx->prior_set) return set_err(ctx, MCALF_ERR_INVALID, "mcalf_set_prior has not been called");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->last.path = MCALF_PATH_DEVICE; ctx->last.pinned_in = ctx->last.pinned_out = 0;
     return launch(ctx, kModeLogL, dcube, batch, 0, 0, dlogL, nullptr, (hipStream_t)stream, true, dtheta);
 }
 

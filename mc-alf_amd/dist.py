@@ -126,36 +126,73 @@ def sharded_loglike(evaluate: Callable[[int, int, torch.Tensor], None], batch: i
 
 class InLibGather:
     """The same exchange done INSIDE the library: the context owns an RCCL communicator and
-    `mcalf_loglike_gather_device` enqueues kernels + one grouped send/receive on the launch stream -- no Python
-    and no host round trip in the step.  torch.distributed (any backend) is used once, to hand rank 0's 128-byte
-    RCCL id to the other ranks; without an initialised process group this is a one-rank communicator.
+    `mcalf_loglike_gatherv_device` enqueues the kernels on the launch stream and one grouped send / receive on a
+    context-owned stream behind them -- no Python and no host round trip in the step.  torch.distributed (any
+    backend) is used once, to hand the root's 128-byte RCCL id to the other ranks; without an initialised process
+    group this is a one-rank communicator.
 
-    Every rank evaluates `batch_local` rows (equal shards); `self.all` on `root` holds [world * batch_local]."""
+    `batch` is the JOB-WIDE number of rows; shards are the contiguous blocks of `shard_bounds` (ragged allowed).
+    Two (local, all) buffer pairs alternate so that the exchange of step k overlaps the kernels of step k+1
+    (`mcalf_comm_set_overlap`); `finish()` joins the outstanding exchanges and returns the last gathered vector
+    on `root` (None elsewhere).  `root` is a rank of `group`."""
 
-    def __init__(self, fit, batch_local: int, device, root: int = 0, group=None):
-        self.fit, self.root, self.n = fit, root, int(batch_local)
+    def __init__(self, fit, batch: int, device, root: int = 0, group=None, depth: int = 2):
+        self.fit, self.root = fit, int(root)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if not (0 <= self.root < self.world):
+            raise ValueError(f"root {root} is not a rank of a {self.world}-rank group")
+        self.batch = int(batch)
+        self.counts = shard_counts(self.batch, self.world)
+        self.lo, self.hi = shard_bounds(self.batch, self.world, self.rank)
+        self.n = self.hi - self.lo
         ident = [None]
-        if self.rank == root:
+        if self.rank == self.root:
             buf = C.create_string_buffer(_lib.MCALF_COMM_ID_BYTES)
             _lib.check(fit._lib.mcalf_comm_unique_id(buf))
             ident[0] = buf.raw
         if self.world > 1:
-            dist.broadcast_object_list(ident, src=root, group=group)
+            # broadcast_object_list takes the GLOBAL rank of the source, `root` is a rank of `group`
+            src = dist.get_global_rank(group, self.root) if group is not None else self.root
+            dist.broadcast_object_list(ident, src=src, group=group)
         self._id = C.create_string_buffer(ident[0], _lib.MCALF_COMM_ID_BYTES)
         _lib.check(fit._lib.mcalf_comm_init(fit._ctx, self._id, self.world, self.rank), fit._ctx)
-        self.local = torch.empty(self.n, dtype=torch.float64, device=device)
-        self.all = torch.empty(self.n * self.world, dtype=torch.float64, device=device) if self.rank == root else None
+        self.depth = 2 if depth >= 2 else 1
+        _lib.check(fit._lib.mcalf_comm_set_overlap(fit._ctx, 1 if self.depth == 2 else 0), fit._ctx)
+        self._counts = (C.c_int64 * self.world)(*self.counts)
+        self._local = [torch.empty(max(self.n, 1), dtype=torch.float64, device=device)[: self.n] for _ in range(self.depth)]
+        self._all = ([torch.empty(self.batch, dtype=torch.float64, device=device) for _ in range(self.depth)]
+                     if self.rank == self.root else [None] * self.depth)
+        self._slot, self._last = 0, None
+
+    @property
+    def local(self) -> torch.Tensor:
+        """This rank's logL block of the most recent step."""
+        return self._local[self._last if self._last is not None else 0]
+
+    @property
+    def all(self) -> Optional[torch.Tensor]:
+        """The gathered vector of the most recent step on `root` (valid after `finish()` or a stream sync)."""
+        return self._all[self._last if self._last is not None else 0]
 
     def step(self, dP: torch.Tensor, stream: Optional[torch.cuda.Stream] = None) -> None:
-        """Evaluate this rank's rows `dP` [batch_local][ndim] and enqueue the gather (asynchronous)."""
+        """Evaluate this rank's rows `dP` [hi - lo][ndim] and enqueue the gather (asynchronous)."""
         st = stream if stream is not None else torch.cuda.current_stream()
-        rc = self.fit._lib.mcalf_loglike_gather_device(
-            self.fit._ctx, dP.data_ptr(), self.n, self.local.data_ptr(),
-            self.all.data_ptr() if self.all is not None else None, self.root, C.c_void_p(st.cuda_stream))
+        k = self._slot
+        rc = self.fit._lib.mcalf_loglike_gatherv_device(
+            self.fit._ctx, dP.data_ptr() if self.n else None, self.n, self._local[k].data_ptr() if self.n else None,
+            self._all[k].data_ptr() if self._all[k] is not None else None, self._counts, self.root,
+            C.c_void_p(st.cuda_stream))
+        self._last, self._slot = k, (k + 1) % self.depth
         if rc:
             _lib.check(rc, self.fit._ctx)
+
+    def finish(self, stream: Optional[torch.cuda.Stream] = None) -> Optional[torch.Tensor]:
+        """Make `stream` wait for every outstanding exchange, synchronise it, return the last gathered vector."""
+        st = stream if stream is not None else torch.cuda.current_stream()
+        _lib.check(self.fit._lib.mcalf_comm_join(self.fit._ctx, C.c_void_p(st.cuda_stream)), self.fit._ctx)
+        st.synchronize()
+        return self.all
 
     def close(self):
         _lib.check(self.fit._lib.mcalf_comm_destroy(self.fit._ctx), self.fit._ctx)

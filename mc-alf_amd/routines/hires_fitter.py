@@ -243,6 +243,13 @@ class als_fitter:
     def chunks_for(self, batch):
         return int(self._lib.mcalf_get_chunks(self._ctx, int(batch)))
 
+    def last_launch(self):
+        """What the last call of this context did (`mcalf_last_launch`): entry plan, row blocks, whether the fused
+        kernel ran as the persistent grid, its grid and work-item count."""
+        info = _lib.mcalf_launch_info_t()
+        _lib.check(self._lib.mcalf_last_launch(self._ctx, C.byref(info)), self._ctx)
+        return info
+
     def __del__(self):
         try:
             self.close()

@@ -40,7 +40,8 @@ def test_row_blocks_do_not_change_results(cfg, n):
         fit.set_chunks(0)
         assert fit.chunks_for(n) == 1
         assert np.array_equal(_device_logl(fit, dP, n), whole)
-        # host-pointer entry: pageable arrays (staged), page-locked arrays (direct DMA), every block count
+        # host-pointer entry at these sizes: the zero-copy small path (batch * ndim <= 65536 doubles); the pipelined
+        # path -- pageable / page-locked, every block plan -- is covered by tests/test_gpu_timed_path.py
         for k in (0, 1, 2, 5):
             fit.set_chunks(k)
             assert np.array_equal(fit.loglike_batch(P), whole)
@@ -95,23 +96,3 @@ def test_resolution_beyond_the_provisioned_kernel_is_not_a_valid_likelihood():
         assert np.isnan(fit.model_batch(P[1:2])).all()
         with pytest.raises(ValueError, match="specres"):
             fit.reconstruct_onecomp(30.0, 1.0, 13.5, 3.0, 20.0)
-
-
-def test_persistent_grid_and_lines_per_barrier_do_not_change_results(monkeypatch):
-    """The persistent work-item queue (MCALF_PERSIST) and the number of lines folded per barrier
-    (MCALF_LINES_PER_SYNC) are scheduling choices: every live point's arithmetic is the same, so logL is bit-equal
-    across them -- single-tile (C, 2600 items: persistent grid) and multi-tile (E, 5 tiles per point)."""
-    for cfg, n in (("C", 2600), ("E", 450)):
-        kw, _, seed = workloads.config(cfg, oracle_synth)
-        P = workloads.draw_P(kw, n, np.random.default_rng(seed + 77), damped=2 if cfg == "E" else 0)
-        results = {}
-        for persist in ("1", "0"):
-            for lps in ("4", "5"):
-                monkeypatch.setenv("MCALF_PERSIST", persist)
-                monkeypatch.setenv("MCALF_LINES_PER_SYNC", lps)
-                with mcalf_amd.als_fitter(None, **kw) as fit:
-                    results[(persist, lps)] = fit.loglike_batch(P)
-        ref = results[("1", "4")]
-        assert np.isfinite(ref).all()
-        for key, val in results.items():
-            assert np.array_equal(val, ref), key

@@ -1,0 +1,106 @@
+"""GPU: the N > 1 branch of the in-library gather (mcalf_loglike_gatherv_device: grouped receives on the root, send
+on the others, ragged counts, the exchange stream with and without overlap, the NaN-block error path) driven by TWO
+processes on the one GPU of a box.  RCCL itself refuses two ranks on one device, so the transport is the test-only
+stand-in tests/stubs/fake_rccl.cpp behind MCALF_RCCL_LIB: this checks the library's control flow, offsets and error
+handling, NOT RCCL -- RCCL with more than one rank runs only on the driver's multi-GPU node."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import mcalf_amd
+from mcalf_amd import _lib, workloads
+from cases import oracle_synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def fake_rccl(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.run([hipcc, "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out,
+                    os.path.join(ROOT, "tests", "stubs", "fake_rccl.cpp"), "-lrt"], check=True, capture_output=True)
+    return out
+
+
+def _run(mode, work, fake):
+    env = dict(os.environ, MCALF_RCCL_LIB=fake, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MCALF_TEST_FAIL_PREFLIGHT", None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gather_worker.py"), str(r), "2", work, mode],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank hung")
+        outs.append((p.returncode, se[-1500:]))
+    assert all(rc == 0 for rc, _ in outs), outs
+    return [json.load(open(os.path.join(work, f"rank{r}.json"))) for r in range(2)]
+
+
+def _expected():
+    kw, _, seed = workloads.config("C", oracle_synth)
+    P = workloads.draw_P(kw, 1001, np.random.default_rng(seed + 99))
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        return fit.loglike_batch(P)
+
+
+def test_two_ranks_ragged_gather_equals_the_single_process_result(tmp_path, fake_rccl):
+    want = _expected()
+    r0, r1 = _run("ok", str(tmp_path), fake_rccl)
+    assert r0["codes"] == [0] * 6 and r1["codes"] == [0] * 6
+    assert r0["comm"] == [2, 0] and r1["comm"] == [2, 1]
+    assert np.array_equal(np.array(r0["plain"]), want)              # 501 + 500 rows, bit for bit
+    for k in range(2):                                               # both buffer pairs of the overlapped steps
+        assert np.array_equal(np.array(r0["overlap"][k]), want)
+
+
+def test_a_rank_that_fails_locally_sends_nans_and_nobody_hangs(tmp_path, fake_rccl):
+    want = _expected()
+    r0, r1 = _run("fail", str(tmp_path), fake_rccl)
+    assert r0["codes"] == [0] * 6                                    # the root is fine ...
+    assert r1["codes"] == [_lib.MCALF_ERR_NOMEM] * 6                 # ... rank 1 reports its failure every time
+    assert "NaN" in r1["err"] and "MCALF_TEST_FAIL_PREFLIGHT" in r1["err"]
+    got = np.array(r0["plain"])
+    assert np.array_equal(got[:501], want[:501]) and np.isnan(got[501:]).all()
+    for k in range(2):
+        g = np.array(r0["overlap"][k])
+        assert np.array_equal(g[:501], want[:501]) and np.isnan(g[501:]).all()
+
+
+def test_argument_errors_return_a_code_and_the_context_destroys_cleanly():
+    """One-rank communicator, real RCCL library: a count that contradicts batch_local, a missing dlogL_all on the
+    root and a bad root are refused before anything is enqueued; the communicator stays usable afterwards."""
+    import ctypes as C
+    import torch
+    kw, _, seed = workloads.config("C", oracle_synth)
+    P = workloads.draw_P(kw, 64, np.random.default_rng(seed + 5))
+    dP = torch.from_numpy(P).cuda()
+    out = torch.zeros(64, dtype=torch.float64, device="cuda")
+    full = torch.zeros(64, dtype=torch.float64, device="cuda")
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        want = fit.loglike_batch(P)
+        lib, ctx = fit._lib, fit._ctx
+        buf = C.create_string_buffer(_lib.MCALF_COMM_ID_BYTES)
+        _lib.check(lib.mcalf_comm_unique_id(buf))
+        _lib.check(lib.mcalf_comm_init(ctx, buf, 1, 0), ctx)
+        bad = (C.c_int64 * 1)(63)
+        assert lib.mcalf_loglike_gatherv_device(ctx, dP.data_ptr(), 64, out.data_ptr(), full.data_ptr(), bad, 0, None) == _lib.MCALF_ERR_INVALID
+        assert lib.mcalf_loglike_gatherv_device(ctx, dP.data_ptr(), 64, out.data_ptr(), None, None, 0, None) == _lib.MCALF_ERR_INVALID
+        assert lib.mcalf_loglike_gatherv_device(ctx, dP.data_ptr(), 64, out.data_ptr(), full.data_ptr(), None, 1, None) == _lib.MCALF_ERR_INVALID
+        assert lib.mcalf_loglike_gatherv_device(ctx, dP.data_ptr(), -1, out.data_ptr(), full.data_ptr(), None, 0, None) == _lib.MCALF_ERR_INVALID
+        good = (C.c_int64 * 1)(64)
+        _lib.check(lib.mcalf_loglike_gatherv_device(ctx, dP.data_ptr(), 64, out.data_ptr(), full.data_ptr(), good, 0, None), ctx)
+        torch.cuda.synchronize()
+        assert np.array_equal(full.cpu().numpy(), want) and np.array_equal(out.cpu().numpy(), want)
+        _lib.check(lib.mcalf_comm_destroy(ctx), ctx)

@@ -1,0 +1,133 @@
+"""GPU: the path that bench.py times -- `mcalf_loglike_batch_device`, ONE persistent launch over the whole batch --
+against the oracles on every row of BASELINE configs C (4096 rows) and D (32768 rows), with the launch mode read
+back from the library (`mcalf_last_launch`) instead of inferred from the batch size; and the pipelined host-pointer
+entry (pageable / page-locked, every block plan) asserted to be the path taken."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import mcalf_amd
+from mcalf_amd import _lib, workloads
+from cases import oracle_synth, problem_from_kwargs
+from oracle import c_oracle
+from oracle import numpy_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+LOGL_ATOL = 1e-4          # BASELINE.json north_star: logL within 1e-4 absolute
+
+
+def _device_logl(fit, dP, n):
+    out = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(fit._lib.mcalf_loglike_batch_device(fit._ctx, dP.data_ptr(), n, out.data_ptr(), st), fit._ctx)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("cfg", ["C", "D"])
+def test_one_persistent_launch_over_the_full_batch_against_both_oracles(cfg):
+    """Exactly what bench.py times (config C: its N = 1 headline; config D: the strong-scaling N = 1 leg and, in
+    4096-row shards, every GPU's share at N = 8): device entry, one launch, persistent grid, ordered hand-out."""
+    kw, batch, seed = workloads.config(cfg, oracle_synth)
+    assert (batch, seed) == {"C": (4096, 2), "D": (32768, 3)}[cfg]
+    P = workloads.draw_P(kw, batch, np.random.default_rng(seed))
+    prob = problem_from_kwargs(kw)
+    dP = torch.from_numpy(P).cuda()
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        _lib.check(fit._lib.mcalf_reserve(fit._ctx, batch), fit._ctx)
+        got = _device_logl(fit, dP, batch)
+        ll = fit.last_launch()
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        assert ll.path == _lib.MCALF_PATH_DEVICE and ll.row_blocks == 1
+        assert ll.persistent == 1 and ll.grid == 2 * cus and ll.items == batch      # ONE persistent launch
+        assert ll.selfhalo == 1 and ll.lines_per_sync == 5
+        again = _device_logl(fit, dP, batch)                     # the queue hands items out in another order:
+        assert np.array_equal(got, again)                        # values do not depend on who evaluates what when
+    assert np.isfinite(got).all()
+    co = c_oracle.COracle(prob, threads=min(16, os.cpu_count() or 1))
+    want_c = co.loglike_batch(P)                                 # EVERY row
+    assert np.abs(got - want_c).max() < LOGL_ATOL
+    assert (np.abs(got - want_c) / np.abs(want_c)).max() < 1e-10
+    idx = np.arange(0, batch, batch // 32)                       # a spread of rows against the numpy / scipy oracle
+    want = o.loglike_batch(prob, P[idx])
+    assert np.abs(got[idx] - want).max() < LOGL_ATOL
+
+
+def test_persistent_switch_is_really_taken_and_changes_nothing(monkeypatch):
+    """MCALF_PERSIST / MCALF_ORDER / MCALF_LINES_PER_SYNC are scheduling choices.  The mode is read back from the
+    library for every context (device entry, >= 4 items per workgroup slot so that the persistent grid applies)."""
+    for cfg, n in (("C", 2600), ("E", 450)):
+        kw, _, seed = workloads.config(cfg, oracle_synth)
+        P = workloads.draw_P(kw, n, np.random.default_rng(seed + 77), damped=2 if cfg == "E" else 0)
+        dP = torch.from_numpy(P).cuda()
+        results = {}
+        for persist, order, lps in (("1", "1", "4"), ("1", "1", "5"), ("1", "0", "4"), ("0", "1", "4"), ("0", "0", "5")):
+            monkeypatch.setenv("MCALF_PERSIST", persist)
+            monkeypatch.setenv("MCALF_ORDER", order)
+            monkeypatch.setenv("MCALF_LINES_PER_SYNC", lps)
+            with mcalf_amd.als_fitter(None, **kw) as fit:
+                results[(persist, order, lps)] = _device_logl(fit, dP, n)
+                ll = fit.last_launch()
+                items = n * fit.info.ntiles
+                assert ll.items == items and items >= 4 * 512
+                assert ll.persistent == int(persist), (cfg, persist)
+                assert ll.grid == (ll.grid if persist == "1" else items) and (persist == "0" or ll.grid < items)
+                assert ll.lines_per_sync in (4, 5)
+        ref = results[("1", "1", "4")]
+        assert np.isfinite(ref).all()
+        for key, val in results.items():
+            assert np.array_equal(val, ref), (cfg, key)
+
+
+def test_pipelined_host_entry_is_the_path_taken_and_is_bit_equal(monkeypatch):
+    """Large scalar-output calls through host pointers (batch * ndim > 65536 doubles) run `run_host_pipelined`:
+    pageable arrays are staged, page-locked ones are used by the copy engines directly and the kernels write logL
+    into the caller's page-locked array.  Every block plan gives the device entry's bits."""
+    kw, _, seed = workloads.config("C", oracle_synth)
+    n = 2600
+    P = workloads.draw_P(kw, n, np.random.default_rng(seed + 13))
+    assert P.size > 65536
+    Ppin = torch.from_numpy(P).pin_memory().numpy()
+    dP = torch.from_numpy(P).cuda()
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        whole = _device_logl(fit, dP, n)
+        assert np.isfinite(whole).all()
+        for k, blocks_pageable, blocks_pinned in ((0, 4, 2), (1, 1, 1), (2, 2, 2), (5, 5, 5)):
+            fit.set_chunks(k)
+            got = fit.loglike_batch(P)
+            ll = fit.last_launch()
+            assert (ll.path, ll.row_blocks, ll.pinned_in, ll.pinned_out) == (_lib.MCALF_PATH_HOST_PIPELINED, blocks_pageable, 0, 0)
+            assert np.array_equal(got, whole), k
+            opin = torch.full((n,), float("nan"), dtype=torch.float64).pin_memory().numpy()
+            fit.loglike_batch(Ppin, out=opin)
+            ll = fit.last_launch()
+            assert (ll.path, ll.row_blocks, ll.pinned_in, ll.pinned_out) == (_lib.MCALF_PATH_HOST_PIPELINED, blocks_pinned, 1, 1)
+            assert np.array_equal(opin, whole), k
+            # mixed: page-locked rows, pageable results
+            mixed = np.full(n, np.nan)
+            fit.loglike_batch(Ppin, out=mixed)
+            assert fit.last_launch().pinned_in == 1 and fit.last_launch().pinned_out == 0
+            assert np.array_equal(mixed, whole)
+            assert np.array_equal(fit.chi2_batch(P), fit.chi2_batch(P[::-1].copy())[::-1])
+        fit.set_chunks(0)
+        # small calls take the zero-copy block instead
+        assert np.array_equal(fit.loglike_batch(P[:100]), whole[:100])
+        assert fit.last_launch().path == _lib.MCALF_PATH_HOST_ZEROCOPY
+    # explicit relative plans; 1 : 1 : 5000 of 2600 rows leaves block 0 EMPTY and one row in block 1
+    for plan in ("1,3,4", "1,1,5000"):
+        monkeypatch.setenv("MCALF_HOST_PLAN", plan)
+        with mcalf_amd.als_fitter(None, **kw) as fit:
+            assert np.array_equal(fit.loglike_batch(P), whole), plan
+            assert fit.last_launch().row_blocks == 3
+    monkeypatch.setenv("MCALF_HOST_PLAN", "1,30,30")
+    kwB, _, seedB = workloads.config("E", oracle_synth)        # E: ndim 49; 1400 rows > 65536 doubles
+    PE = workloads.draw_P(kwB, 1400, np.random.default_rng(seedB + 5), damped=2)
+    with mcalf_amd.als_fitter(None, **kwB) as fit:
+        a = fit.loglike_batch(PE)
+        assert fit.last_launch().path == _lib.MCALF_PATH_HOST_PIPELINED
+        fit.set_chunks(1)
+        assert np.array_equal(fit.loglike_batch(PE), a)
