@@ -514,7 +514,7 @@ def main():
             out["model_output"] = model_leg
         ll = fit.last_launch()
         out["launch"] = {"persistent": bool(ll.persistent), "grid": ll.grid, "items": ll.items,
-                         "lines_per_sync": ll.lines_per_sync, "ordered_handout": os.environ.get("MCALF_ORDER", "1") != "0"}
+                         "lines_per_sync": ll.lines_per_sync, "ordered_handout": bool(ll.ordered)}
         if use_dist:
             out["rccl_ranks"] = rccl_ranks
             out["gather"] = ("library (mcalf_loglike_gatherv_device: kernels on the launch stream, grouped ncclSend/ncclRecv "

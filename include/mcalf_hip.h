@@ -177,6 +177,8 @@ typedef struct {
     int32_t selfhalo;       /* 1: single-tile spectrum, halo entries are copies of the tile's own pixels      */
     int32_t pinned_in;      /* host-pointer entries: the parameter rows were page-locked caller memory        */
     int32_t pinned_out;     /* host-pointer entries: the result array was page-locked caller memory           */
+    int32_t inline_setup;   /* 1: small launch -- ONE kernel, the per-sample set-up ran inside the fused kernel */
+    int32_t ordered;        /* 1: the persistent grid handed the live points out sorted by component count      */
 } mcalf_launch_info_t;
 int mcalf_last_launch(const mcalf_ctx* ctx, mcalf_launch_info_t* info);
 

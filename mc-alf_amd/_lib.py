@@ -80,6 +80,8 @@ class mcalf_launch_info_t(C.Structure):
         ("selfhalo", C.c_int32),
         ("pinned_in", C.c_int32),
         ("pinned_out", C.c_int32),
+        ("inline_setup", C.c_int32),
+        ("ordered", C.c_int32),
     ]
 
 

@@ -460,24 +460,14 @@ __device__ void build_order(const KArgs& a, long batch) {
     }
 }
 
+// The set-up of live point s by ONE wave (`lane` = 0..63): decode, records, taps, header, written through the given
+// pointers -- the context's workspaces in HBM (mcalf_sample_kernel) or the workgroup's own LDS (the one-launch
+// variant of the fused kernel that small calls use).  One body, so both give the same bits.
 template <bool kZeroPad>
-__global__ __launch_bounds__(kSetupBlockMax) void mcalf_sample_kernel(const KArgs a, long batch) {
-    // one WAVE per live point, blockDim.x / 64 live points per workgroup (the waves never synchronise); with an
-    // ordered hand-out workgroup 0 builds the order and the live points start at workgroup 1
-    int blk = blockIdx.x;
-    if (a.order) {
-        if (blk == 0) { build_order<kZeroPad>(a, batch); return; }
-        --blk;
-    }
-    const long s = (long)blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (s >= batch) return;
-    const int lane = threadIdx.x & 63;
-    if (s == 0 && lane == 0) *a.queue = 0u;          // item queue of the fused kernel that follows on the stream
+__device__ __forceinline__ void setup_sample(const KArgs& a, long s, int lane, double* recs, double* taps, bool writeTaps,
+                                             SampleHdr* hdrOut, bool writeTheta) {
     const int rowlen = (a.mode == kModeOneComp) ? 5 : a.ndim;
     const double* p = a.P + (size_t)s * rowlen;
-    double* recs = a.recs + (size_t)s * a.ncl_cap * kRecStride;
-    double* taps = a.taps + (a.taps_shared ? 0 : (size_t)s * (2 * a.n_cap + 8));
-    const bool writeTaps = !a.taps_shared || s == 0;
     // ---- 1. decode the parameter vector ---------------------------------------------------
     double R, cont;
     int nc, nfill_eff;
@@ -490,7 +480,7 @@ __global__ __launch_bounds__(kSetupBlockMax) void mcalf_sample_kernel(const KArg
         R = a.freespecres ? sample_param(a, p, 0) : a.specres_fixed;     // :412-417
         cont = a.freecont ? sample_param(a, p, a.freespecres ? 1 : 0) : a.contval_fixed;   // :419-425
         const double ncv = sample_param(a, p, a.startind);
-        if (a.theta_out)
+        if (a.theta_out && writeTheta)
             for (int i = lane; i < a.ndim; i += 64) a.theta_out[(size_t)s * a.ndim + i] = sample_param(a, p, i);
         // numpy path: int() truncates (:428); JAX path: floor (:616)
         const double nct = kZeroPad ? floor(ncv) : trunc(ncv);
@@ -600,8 +590,25 @@ __global__ __launch_bounds__(kSetupBlockMax) void mcalf_sample_kernel(const KArg
     if (lane == 0) {
         SampleHdr h;
         h.cont = cont; h.bot = bot; h.ncl = ncl; h.n = n; h.bad = bad ? 1 : 0; h.ngeneral = ngen;
-        a.hdr[s] = h;
+        *hdrOut = h;
     }
+}
+
+template <bool kZeroPad>
+__global__ __launch_bounds__(kSetupBlockMax) void mcalf_sample_kernel(const KArgs a, long batch) {
+    // one WAVE per live point, blockDim.x / 64 live points per workgroup (the waves never synchronise); with an
+    // ordered hand-out workgroup 0 builds the order and the live points start at workgroup 1
+    int blk = blockIdx.x;
+    if (a.order) {
+        if (blk == 0) { build_order<kZeroPad>(a, batch); return; }
+        --blk;
+    }
+    const long s = (long)blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= batch) return;
+    const int lane = threadIdx.x & 63;
+    if (s == 0 && lane == 0) *a.queue = 0u;          // item queue of the fused kernel that follows on the stream
+    setup_sample<kZeroPad>(a, s, lane, a.recs + (size_t)s * a.ncl_cap * kRecStride,
+                           a.taps + (a.taps_shared ? 0 : (size_t)s * (2 * a.n_cap + 8)), !a.taps_shared || s == 0, a.hdr + s, true);
 }
 
 // Lines outside the fast path's damping range (flag != 0; none for physical resonance lines).  Kept out
@@ -639,7 +646,7 @@ struct ItemLoads {
 // Issue every global load of work item w (one memory round trip; the record and tap copies run to their
 // provisioned sizes, which do not depend on the header: slots beyond the sample's own counts hold stale
 // values that are never read).
-template <bool kZeroPad, bool selfHalo>
+template <bool kZeroPad, bool selfHalo, bool kInline>
 __device__ __forceinline__ void request_item(const KArgs& a, int w, int tid, ItemLoads& L) {
     // The thread index is laundered through an empty asm so that the (item-invariant) load addresses are formed
     // here, from one register, instead of being hoisted out of the item loop and kept alive -- ~30 registers --
@@ -655,12 +662,14 @@ __device__ __forceinline__ void request_item(const KArgs& a, int w, int tid, Ite
         const int idx = tid + i * kBlock;
         L.treg[i] = (idx < VT_NY * VT_NTOT) ? a.tabs[idx] : 0.0;
     }
-    L.hd = a.hdr[s];
-    const double* gr = a.recs + (size_t)s * recTotal;
-    const double* gt = a.taps + (a.taps_shared ? 0 : (size_t)s * tapTotal);
+    if (!kInline) {                                      // (one-launch variant: the workgroup sets the live point up itself)
+        L.hd = a.hdr[s];
+        const double* gr = a.recs + (size_t)s * recTotal;
+        const double* gt = a.taps + (a.taps_shared ? 0 : (size_t)s * tapTotal);
 #pragma unroll
-    for (int i = 0; i < kRecRegs; ++i) L.rreg[i] = (tid + i * kBlock < recTotal) ? gr[tid + i * kBlock] : 0.0;
-    L.tapreg = (tid < tapTotal) ? gt[tid] : 0.0;
+        for (int i = 0; i < kRecRegs; ++i) L.rreg[i] = (tid + i * kBlock < recTotal) ? gr[tid + i * kBlock] : 0.0;
+        L.tapreg = (tid < tapTotal) ? gt[tid] : 0.0;
+    }
     const int t0 = tileIdx * a.tile;
     const int ext0 = selfHalo ? 0 : t0 - a.n_cap;
 #pragma unroll
@@ -690,7 +699,10 @@ __device__ __forceinline__ void request_item(const KArgs& a, int w, int tid, Ite
 // requested before the likelihood terms of the current one and written to LDS behind the barrier that ends it.
 // Every wave leaves the item loop at the same item count (the queue value is broadcast through LDS), so no wave
 // is ever left behind a barrier.
-template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync>
+// kInline (small calls -- the one-theta-at-a-time solvers): there is no set-up kernel; wave 0 of the workgroup runs
+// setup_sample() for its live point straight into LDS (one launch instead of two on a latency-bound path; every tile of
+// a tiled spectrum repeats the set-up, which costs nothing when the chip is empty).
+template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync, bool kInline>
 __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {
     extern __shared__ __align__(16) double smem[];
     double* sTab = smem;                                   // 2 x kLinesPerSync folded tables
@@ -713,11 +725,11 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     const int nItems = a.nitems;
 
     // ticket -> work item: with an ordered hand-out, ticket t is tile (t % ntiles) of live point order[t / ntiles]
-    constexpr bool kOrdered = kSelfHalo;               // (the host passes a.order only to these instantiations)
+    constexpr bool kOrdered = kSelfHalo && !kInline;   // (the host passes a.order only to these instantiations)
     auto item_of = [&](int t) -> int { return (kOrdered && a.order) ? a.order[t] : t; };
     int w = item_of(blockIdx.x);                       // grid <= nItems
     ItemLoads L;
-    request_item<kZeroPad, kSelfHalo>(a, w, tid0, L);
+    request_item<kZeroPad, kSelfHalo, kInline>(a, w, tid0, L);
 
     while (true) {
         MCALF_STAMP(0);
@@ -765,21 +777,25 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             for (int j = 0; j < kPpt; ++j) segOk |= ((L.tileMask >> (wv + 8 * j)) & 1ULL) << (8 * j);
             segOk = uniform64(segOk);
         }
-        const SampleHdr hd = L.hd;
-        const double cont = hd.cont, bot = hd.bot;
-        const int ncl = hd.ncl, n = hd.n;
-        const bool bad = hd.bad != 0;
+        SampleHdr hd;
+        SampleHdr* sHdr = reinterpret_cast<SampleHdr*>(sRed + 2 * kWaves);   // (one-launch variant; the slot is scratch until the reduction)
+        static_assert(sizeof(SampleHdr) <= kWaves * sizeof(double), "header fits the scratch slot");
+        if (kInline) {
+            if (tid < 64) setup_sample<kZeroPad>(a, s, tid, sRec, sW, true, sHdr, tileIdx == 0);
+        } else {
+            hd = L.hd;
 #pragma unroll
-        for (int i = 0; i < kRecRegs; ++i)
-            if (tid + i * kBlock < recTotal) sRec[tid + i * kBlock] = L.rreg[i];
-        if (recTotal > kRecRegs * kBlock) {
-            const double* gr = a.recs + (size_t)s * recTotal;
-            for (int i = tid + kRecRegs * kBlock; i < recTotal; i += kBlock) sRec[i] = gr[i];
-        }
-        if (tid < tapTotal) sW[tid] = L.tapreg;
-        if (tapTotal > kBlock) {
-            const double* gt = a.taps + (a.taps_shared ? 0 : (size_t)s * tapTotal);
-            for (int i = tid + kBlock; i < tapTotal; i += kBlock) sW[i] = gt[i];
+            for (int i = 0; i < kRecRegs; ++i)
+                if (tid + i * kBlock < recTotal) sRec[tid + i * kBlock] = L.rreg[i];
+            if (recTotal > kRecRegs * kBlock) {
+                const double* gr = a.recs + (size_t)s * recTotal;
+                for (int i = tid + kRecRegs * kBlock; i < recTotal; i += kBlock) sRec[i] = gr[i];
+            }
+            if (tid < tapTotal) sW[tid] = L.tapreg;
+            if (tapTotal > kBlock) {
+                const double* gt = a.taps + (a.taps_shared ? 0 : (size_t)s * tapTotal);
+                for (int i = tid + kBlock; i < tapTotal; i += kBlock) sW[i] = gt[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < kTRegs; ++i) {
@@ -800,8 +816,12 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
 
         MCALF_STAMP(1);
         // ---- 2. tau for this thread's pixels ----------------------------------------------------
+        __syncthreads();                                   // publishes sRec, sW, sT, sNext (and the header of the one-launch variant)
+        if (kInline) hd = *sHdr;
+        const double cont = hd.cont, bot = hd.bot;
+        const int ncl = hd.ncl, n = hd.n;
+        const bool bad = hd.bad != 0;
         const int shift = a.n_cap - n;
-        __syncthreads();                                   // publishes sRec, sW, sT, sNext
         int tNext = 0, wNext = 0;
         if (!kOrdered) {
             tNext = __builtin_amdgcn_readfirstlane(sNext[0]);            // the next ticket ...
@@ -1005,6 +1025,17 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
                         acc += (base + m < tlen && !isnan(term)) ? term : 0.0;                 // np.nansum
                     }
                 }
+            } else if (!kZeroPad && a.mode != kModeLogL && a.mode != kModeChi2 && a.model != nullptr) {
+                // Model output alone (reconstruct_spec / reconstruct_onecomp for a batch, numpy boundary): eight
+                // consecutive pixels per thread, 64 contiguous bytes, nothing else -- same arithmetic as above.
+                double* mrow = a.model + (size_t)s * a.npix + t0 + base;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    double mval = top[m] * ibot;
+                    mval *= cont;                                                              // :447
+                    if (bad) mval = NAN;
+                    if (base + m < tlen) mrow[m] = mval;
+                }
             } else
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
@@ -1038,7 +1069,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         // (unconditional -- the last item of a workgroup re-requests a valid item it never uses -- so that the
         // loads REDEFINE every register of L: behind a condition the old values would have to stay alive through
         // the whole item for the merge)
-        request_item<kZeroPad, kSelfHalo>(a, more ? wNext : w, tid, L);
+        if (!kInline) request_item<kZeroPad, kSelfHalo, kInline>(a, more ? wNext : w, tid, L);   // (one-launch variant: one item per workgroup)
         __builtin_amdgcn_sched_barrier(0);
         if (reduces) {
             acc = wave_sum_to_last(acc);
@@ -1069,7 +1100,7 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
                 pr[0] = ssum; pr[1] = scnt; pr[2] = t4; pr[3] = t5;
             }
         }
-        if (!more) break;                                // wave-uniform: every wave of the workgroup leaves here
+        if (kInline || !more) break;                     // wave-uniform: every wave of the workgroup leaves here
         w = wNext;
     }
 }
@@ -1134,7 +1165,8 @@ struct mcalf_ctx {
     double veto4 = 0, veto5 = 0;
     // geometry
     int n_cap = 0, tile = 0, ntiles = 0, ncl_cap = 0, jax_half = 0, selfhalo = 0, lps = 4;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, lds_bytes_inline = 0;    // (the one-launch variant of small calls folds 4 lines per barrier)
+    int inline_max_items = 0;                      // launches of at most this many work items take the one-launch variant
     // device buffers
     double *d_nu = nullptr, *d_obj = nullptr, *d_ispec2 = nullptr, *d_lgis = nullptr, *d_err = nullptr, *d_tabs = nullptr;
     LineDev* d_lines = nullptr;
@@ -1282,15 +1314,20 @@ extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     delete ctx;
 }
 
-// The eight instantiations of the fused kernel: (JAX semantics, self-halo tile, lines per barrier).
-static const void* fused_kernel_ptr(bool jax, bool selfhalo, int lps) {
-#define MCALF_K(J, S, L) reinterpret_cast<const void*>(&mcalf_fused_kernel<J, S, L>)
-    if (lps == 5) {
-        if (jax) return selfhalo ? MCALF_K(true, true, 5) : MCALF_K(true, false, 5);
-        return selfhalo ? MCALF_K(false, true, 5) : MCALF_K(false, false, 5);
+// The instantiations of the fused kernel: (JAX semantics, self-halo tile, lines per barrier) for batches, and the
+// one-launch variant (set-up inside the kernel, always 4 lines per barrier) for small calls.
+static const void* fused_kernel_ptr(bool jax, bool selfhalo, int lps, bool inl = false) {
+#define MCALF_K(J, S, L, I) reinterpret_cast<const void*>(&mcalf_fused_kernel<J, S, L, I>)
+    if (inl) {
+        if (jax) return selfhalo ? MCALF_K(true, true, 4, true) : MCALF_K(true, false, 4, true);
+        return selfhalo ? MCALF_K(false, true, 4, true) : MCALF_K(false, false, 4, true);
     }
-    if (jax) return selfhalo ? MCALF_K(true, true, 4) : MCALF_K(true, false, 4);
-    return selfhalo ? MCALF_K(false, true, 4) : MCALF_K(false, false, 4);
+    if (lps == 5) {
+        if (jax) return selfhalo ? MCALF_K(true, true, 5, false) : MCALF_K(true, false, 5, false);
+        return selfhalo ? MCALF_K(false, true, 5, false) : MCALF_K(false, false, 5, false);
+    }
+    if (jax) return selfhalo ? MCALF_K(true, true, 4, false) : MCALF_K(true, false, 4, false);
+    return selfhalo ? MCALF_K(false, true, 4, false) : MCALF_K(false, false, 4, false);
 #undef MCALF_K
 }
 
@@ -1377,6 +1414,7 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     ctx->tile = (int)tile;
     ctx->ntiles = (int)ntiles;
     ctx->lds_bytes = (fixed_doubles + (size_t)tile_doubles((int)tile + 2 * ctx->n_cap)) * sizeof(double);
+    ctx->lds_bytes_inline = (fixed_for(4) + (size_t)tile_doubles((int)tile + 2 * ctx->n_cap)) * sizeof(double);
     ctx->selfhalo = (ntiles == 1 && ctx->n_cap < ctx->npix) ? 1 : 0;
 
     // spectrum arrays (float64 host arithmetic identical to the reference's numpy expressions)
@@ -1495,7 +1533,9 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     const void* kernels[] = {fused_kernel_ptr(false, false, 4), fused_kernel_ptr(false, true, 4),
                              fused_kernel_ptr(true, false, 4),  fused_kernel_ptr(true, true, 4),
                              fused_kernel_ptr(false, false, 5), fused_kernel_ptr(false, true, 5),
-                             fused_kernel_ptr(true, false, 5),  fused_kernel_ptr(true, true, 5)};
+                             fused_kernel_ptr(true, false, 5),  fused_kernel_ptr(true, true, 5),
+                             fused_kernel_ptr(false, false, 4, true), fused_kernel_ptr(false, true, 4, true),
+                             fused_kernel_ptr(true, false, 4, true),  fused_kernel_ptr(true, true, 4, true)};
     for (const void* k : kernels)
         HIP_TRY(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -1508,6 +1548,8 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         const char* pe = std::getenv("MCALF_PERSIST");
         if (pe && *pe) ctx->persist = std::atoi(pe) != 0;
         if (const char* oe = std::getenv("MCALF_ORDER")) ctx->ordered = std::atoi(oe) != 0;
+        ctx->inline_max_items = 2 * ctx->num_cu;                    // launches that fit the chip in one round of workgroups
+        if (const char* ie = std::getenv("MCALF_INLINE_MAX")) ctx->inline_max_items = std::max(0, std::atoi(ie));
         if (const char* sb = std::getenv("MCALF_SETUP_BLOCK")) {      // diagnostic: geometry of the set-up kernel
             const int v = std::atoi(sb);
             if (v >= 64 && v <= kSetupBlockMax && v % 64 == 0) ctx->setup_block = v;
@@ -1633,23 +1675,34 @@ static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0
     const int64_t slots = 2LL * ctx->num_cu;
     a.persist = (ctx->persist && a.nitems >= 4 * slots) ? 1 : 0;
     a.queue = ctx->d_queue + chunk;
-    a.order = (a.persist && ctx->ordered && ctx->selfhalo && mode != kModeOneComp) ? ctx->d_order + row0 : nullptr;
+    // Ordered hand-out while a slot sees at most 16 items: measured on MI355X, config C's spectrum, -2.2 % kernel time
+    // at 8 items per slot (4096 live points) and nothing at 64 (32768), where the ordering workgroup -- its keys no
+    // longer fit its registers -- would lengthen the set-up kernel by 47 us instead.
+    a.order = (a.persist && ctx->ordered && ctx->selfhalo && mode != kModeOneComp && a.nitems <= 16 * slots)
+                  ? ctx->d_order + row0 : nullptr;
     const dim3 grid((unsigned)(a.persist ? slots : a.nitems)), block(kBlock);
     ctx->last.persistent = a.persist; ctx->last.grid = (int32_t)grid.x; ctx->last.items = a.nitems;
-    ctx->last.lines_per_sync = ctx->lps; ctx->last.selfhalo = ctx->selfhalo;
-    const int per_wg = ctx->setup_block / 64;                 // live points per set-up workgroup (one wave each)
-    const dim3 sgrid((unsigned)((nrows + per_wg - 1) / per_wg) + (a.order ? 1u : 0u)), sblock((unsigned)ctx->setup_block);
-    if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX)
-        hipLaunchKernelGGL(mcalf_sample_kernel<true>, sgrid, sblock, 0, stream, a, (long)nrows);
-    else
-        hipLaunchKernelGGL(mcalf_sample_kernel<false>, sgrid, sblock, 0, stream, a, (long)nrows);
-    HIP_TRY(ctx, hipGetLastError());
+    ctx->last.lines_per_sync = ctx->lps; ctx->last.selfhalo = ctx->selfhalo; ctx->last.ordered = a.order ? 1 : 0;
+    // Small launches (the one-theta-at-a-time solvers, a handful of live points): ONE kernel, every workgroup sets
+    // its live point up itself (mcalf_fused_kernel<..., kInline = true>) -- the set-up kernel and the dependent-launch
+    // gap behind it are a fifth of such a call's latency.  Same set-up code, same bits.
+    const bool inl = !a.persist && a.nitems <= ctx->inline_max_items;
+    ctx->last.inline_setup = inl ? 1 : 0;
+    if (!inl) {
+        const int per_wg = ctx->setup_block / 64;             // live points per set-up workgroup (one wave each)
+        const dim3 sgrid((unsigned)((nrows + per_wg - 1) / per_wg) + (a.order ? 1u : 0u)), sblock((unsigned)ctx->setup_block);
+        if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX)
+            hipLaunchKernelGGL(mcalf_sample_kernel<true>, sgrid, sblock, 0, stream, a, (long)nrows);
+        else
+            hipLaunchKernelGGL(mcalf_sample_kernel<false>, sgrid, sblock, 0, stream, a, (long)nrows);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     const bool timed = timed_ok && ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used], stream));
     {
         void* kargs[] = {(void*)&a};
-        HIP_TRY(ctx, hipLaunchKernel(fused_kernel_ptr(ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX, ctx->selfhalo != 0, ctx->lps),
-                                     grid, block, kargs, ctx->lds_bytes, stream));
+        HIP_TRY(ctx, hipLaunchKernel(fused_kernel_ptr(ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX, ctx->selfhalo != 0, ctx->lps, inl),
+                                     grid, block, kargs, inl ? ctx->lds_bytes_inline : ctx->lds_bytes, stream));
     }
     HIP_TRY(ctx, hipGetLastError());
     if (timed) {

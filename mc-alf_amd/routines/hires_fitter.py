@@ -1,14 +1,18 @@
 """Host-side mirror of `mcalf.routines.hires_fitter.als_fitter` for the likelihood hot path.
 
 Same class name, constructor keywords, method names, argument order and return
-conventions as the reference (hires_fitter.py:30-518), so an existing solver driver can
-switch `from mcalf.routines import hires_fitter` to this module unchanged.  Every
-likelihood / model method is a batch-of-one call into the HIP library
-(`libmcalf_hip.so`); `loglike_batch` / `model_batch` are the vectorised entries.
+conventions as the reference (hires_fitter.py:30-518) for everything the solver branches of
+cli.py call on the likelihood path, so the solve step of an existing driver can switch
+`from mcalf.routines import hires_fitter` to this module.  Every likelihood / model method is
+a batch-of-one call into the HIP library (`libmcalf_hip.so`); `loglike_batch` /
+`model_batch` are the vectorised entries.
 
-What is NOT here (out of scope): solver dispatch, plotting, chain
-readers (`pc_analyzer`, `get_parnames`), the prior log-density (`lnprior`, which no solver branch calls).  linetools is replaced by an explicit `linepars=` argument
-plus a tiny built-in table (`LINE_TABLE`).
+NOT a complete replacement of the reference module (out of scope; the
+list a maintainer needs is in INTEGRATION.md section 2): no solver dispatch, no plotting, no
+chain readers -- the module-level `pc_analyzer` and `get_parnames` (hires_fitter.py:704-760),
+which cli.py:345-348 calls after a PolyChord run, stay in `mcalf` -- and no prior log-density (`lnprior` and the `__call__`
+built on it, hires_fitter.py:218-234,509-518, which no solver branch calls).  linetools is
+replaced by an explicit `linepars=` argument plus a tiny built-in table (`LINE_TABLE`).
 """
 from __future__ import annotations
 
@@ -453,7 +457,12 @@ class als_fitter:
             allN = p[self.startind::3]
             allz = p[self.startind + 1::3]
             okN = (allz < 10)
-            allN = 10 ** allN[okN]
+            try:
+                allN = 10 ** allN[okN]
+            except IndexError as exc:
+                raise IndexError(f"{exc} -- calc_N(reference_indexing=True) evaluates the reference's expressions as "
+                                 "written (hires_fitter.py:499-503), which fail like this for every valid parameter "
+                                 "vector; pass reference_indexing=False for the total column density") from exc
             return np.log10(np.sum(allN))
         allN = p[self.startind + 1::3]
         allz = p[self.startind + 2::3]

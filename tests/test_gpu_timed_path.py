@@ -45,6 +45,7 @@ def test_one_persistent_launch_over_the_full_batch_against_both_oracles(cfg):
         assert ll.path == _lib.MCALF_PATH_DEVICE and ll.row_blocks == 1
         assert ll.persistent == 1 and ll.grid == 2 * cus and ll.items == batch      # ONE persistent launch
         assert ll.selfhalo == 1 and ll.lines_per_sync == 5
+        assert ll.ordered == (1 if cfg == "C" else 0)           # ordered hand-out up to 16 items per workgroup slot
         again = _device_logl(fit, dP, batch)                     # the queue hands items out in another order:
         assert np.array_equal(got, again)                        # values do not depend on who evaluates what when
     assert np.isfinite(got).all()
@@ -131,3 +132,45 @@ def test_pipelined_host_entry_is_the_path_taken_and_is_bit_equal(monkeypatch):
         assert fit.last_launch().path == _lib.MCALF_PATH_HOST_PIPELINED
         fit.set_chunks(1)
         assert np.array_equal(fit.loglike_batch(PE), a)
+
+
+@pytest.mark.parametrize("cfg,conv", [("A", "numpy"), ("C", "numpy"), ("E", "numpy"), ("C", "jax"), ("E", "jax")])
+def test_one_launch_variant_of_small_calls_gives_the_two_kernel_bits(cfg, conv, monkeypatch):
+    """Calls of up to 2 x CUs work items (the one-theta-at-a-time solvers) run ONE kernel whose workgroups set their
+    live point up themselves; larger ones run set-up kernel + fused kernel.  Same set-up code: a live point's value
+    must not depend on the size of the batch it arrives in -- logL, chi2, model, single components, cube input."""
+    kw, _, seed = workloads.config(cfg, oracle_synth)
+    kw = dict(kw, conv_mode=conv)
+    rng = np.random.default_rng(seed + 321)
+    P = workloads.draw_P(kw, 9, rng, damped=2 if cfg == "E" else 0)
+    out = {}
+    for inline_max in ("0", None):
+        if inline_max is None:
+            monkeypatch.delenv("MCALF_INLINE_MAX", raising=False)
+        else:
+            monkeypatch.setenv("MCALF_INLINE_MAX", inline_max)
+        with mcalf_amd.als_fitter(None, **kw) as fit:
+            res = []
+            for n in (1, 2, 9):
+                res.append(fit.loglike_batch(P[:n]))
+                assert fit.last_launch().inline_setup == (0 if inline_max == "0" else 1)
+            res.append(fit.chi2_batch(P[:3]))
+            res.append(fit.model_batch(P[:2]))
+            assert fit.last_launch().inline_setup == (0 if inline_max == "0" else 1)
+            res.append(fit.model_batch(P[:2], targonly=True))
+            res.append(fit.onecomp_batch(np.array([[8.0, 1.0, 13.5, P[0][fit.startind + 2], 20.0]]), line=0))
+            res.append(fit.onecomp_batch(np.array([[7.5, 0.97, 13.1, P[0][fit.startind + 2], 12.0]]), fill=True))
+            cubes = rng.random((5, fit.ndim))
+            th, ll = fit.loglike_cube_batch(cubes)
+            res += [th, ll]
+            res.append(np.array([fit.lnlhood_pc(P[3])[0], fit.lnlhood_dy(P[4])]))
+            out[inline_max] = res
+    for a, b in zip(out["0"], out[None]):
+        assert np.array_equal(a, b, equal_nan=True)
+    # ... and a large batch (two-kernel path, persistent grid for C) gives these rows the same bits
+    big = workloads.draw_P(kw, 2600 if cfg != "E" else 600, rng, damped=2 if cfg == "E" else 0)
+    big[:9] = P
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        got = fit.loglike_batch(big)
+        assert fit.last_launch().inline_setup == 0
+    assert np.array_equal(got[:9], out[None][2])

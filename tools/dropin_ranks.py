@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Drop-in mode under several solver ranks (what BASELINE's north-star calls "drops into the existing solvers
+unchanged"): R processes -- PolyChord's MPI workers, cli.py:37-41,110 -- each with its own als_fitter context on the
+ONE GPU of a box, each calling `lnlhood_pc(theta)` serially, one theta per call.  Reports per-call latency and the
+aggregate logL/s for every R, with a parity check (oracle) and a cross-process bit-equality check in every run.
+
+    python tools/dropin_ranks.py [--config B] [--ranks 1,2,4,6] [--calls 2000] [--out profiles/r03_dropin.json]
+
+The parent never touches the GPU (a GPU box admits at most 6 processes on its card at once)."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def worker(cfg, rank, nranks, calls, work):
+    import numpy as np
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import mcalf_amd
+    from mcalf_amd import workloads
+    from cases import oracle_synth, problem_from_kwargs
+    from oracle import numpy_oracle as orc
+
+    kw, _, seed = workloads.config(cfg, oracle_synth)
+    common = workloads.draw_P(kw, 32, np.random.default_rng(seed + 1000), damped=2 if cfg == "E" else 0)   # same in every rank
+    own = workloads.draw_P(kw, calls, np.random.default_rng(seed + 2000 + rank), damped=2 if cfg == "E" else 0)
+    fit = mcalf_amd.als_fitter(None, **kw)
+    for p in own[:50]:
+        fit.lnlhood_pc(p)
+    open(os.path.join(work, f"ready{rank}"), "w").close()
+    t0 = time.time()
+    while not os.path.exists(os.path.join(work, "go")):
+        assert time.time() - t0 < 120
+        time.sleep(0.0005)
+    lat = np.empty(calls)
+    tb = time.perf_counter()
+    for i, p in enumerate(own):
+        t1 = time.perf_counter()
+        fit.lnlhood_pc(p)
+        lat[i] = time.perf_counter() - t1
+    wall = time.perf_counter() - tb
+    shared = [fit.lnlhood_pc(p)[0] for p in common]                      # while the other ranks may still be running
+    prob = problem_from_kwargs(kw)
+    want = np.array([orc.lnlhood_worker(prob, p) for p in common[:8]])
+    res = {"rank": rank, "calls": calls, "wall_s": wall, "us_mean": float(lat.mean() * 1e6), "us_median": float(np.median(lat) * 1e6),
+           "us_p99": float(np.percentile(lat, 99) * 1e6), "shared_logL": shared,
+           "max_abs_dlogL_vs_oracle": float(np.abs(np.array(shared[:8]) - want).max())}
+    fit.close()
+    with open(os.path.join(work, f"res{rank}.json"), "w") as fh:
+        json.dump(res, fh)
+
+
+def run(cfg, nranks, calls):
+    work = tempfile.mkdtemp(prefix="mcalf_dropin_")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", cfg, str(r), str(nranks), str(calls), work],
+                              env=env) for r in range(nranks)]
+    t0 = time.time()
+    while not all(os.path.exists(os.path.join(work, f"ready{r}")) for r in range(nranks)):
+        if time.time() - t0 > 300 or any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                p.kill()
+            raise SystemExit("a worker did not come up")
+        time.sleep(0.01)
+    open(os.path.join(work, "go"), "w").close()
+    for p in procs:
+        if p.wait(timeout=600) != 0:
+            raise SystemExit("a worker failed")
+    res = [json.load(open(os.path.join(work, f"res{r}.json"))) for r in range(nranks)]
+    same = all(r["shared_logL"] == res[0]["shared_logL"] for r in res)
+    return {"ranks": nranks, "calls_per_rank": calls,
+            "aggregate_logL_per_s": sum(r["calls"] / r["wall_s"] for r in res),
+            "us_per_call_mean": sum(r["us_mean"] for r in res) / nranks,
+            "us_per_call_median": sorted(r["us_median"] for r in res)[nranks // 2],
+            "us_per_call_p99_max": max(r["us_p99"] for r in res),
+            "bit_equal_across_ranks": same, "shared_logL_rank0": res[0]["shared_logL"],
+            "max_abs_dlogL_vs_oracle": max(r["max_abs_dlogL_vs_oracle"] for r in res)}
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--worker":
+        worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6])
+        return
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="B")
+    ap.add_argument("--ranks", default="1,2,4,6")
+    ap.add_argument("--calls", type=int, default=2000)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    rows = [run(args.config, int(r), args.calls) for r in args.ranks.split(",")]
+    ref = rows[0]["shared_logL_rank0"]
+    out = {"what": "R solver ranks, one als_fitter context each on ONE MI355X, lnlhood_pc(theta) one theta per call "
+                   "(PolyChord's MPI workers, cli.py:37-41,110)", "config": args.config, "runs": rows,
+           "bit_equal_across_runs": all(r["shared_logL_rank0"] == ref for r in rows)}
+    for r in rows:
+        del r["shared_logL_rank0"]
+        print("R = %d: %.1f us per call (median %.1f, worst p99 %.1f), %.0f logL/s aggregate, bit-equal %s, |dlogL| vs oracle %.1e"
+              % (r["ranks"], r["us_per_call_mean"], r["us_per_call_median"], r["us_per_call_p99_max"], r["aggregate_logL_per_s"],
+                 r["bit_equal_across_ranks"], r["max_abs_dlogL_vs_oracle"]))
+    if args.out:
+        with open(args.out, "w") as fh:
+            json.dump(out, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()

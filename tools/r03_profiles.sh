@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-3 measurement set for one BASELINE config on ONE lease (GPU box): the bench line, the rocprofv3 kernel summary
+# of the same command (one fused launch per step), the PMC passes (each --pmc set its own run, no trace domains), the
+# instruction-issue micro-benchmark.  Usage: tools/r03_profiles.sh <config> <outdir> [steps]
+cfg=${1:-C}; out=${2:-gpurun_out/r03_prof_$cfg}; steps=${3:-50}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p "$out"
+timeout -k 10 600 python bench.py --config $cfg --steps $steps > "$out/bench.json" 2> "$out/bench.err" || echo "bench failed"
+common="--config $cfg --steps $steps --warmup 5 --cpu-seconds 0 --no-host-api --no-strong-ref --no-model-leg"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/ktrace" --output-format csv -- python3 bench.py $common > "$out/ktrace_bench.json" 2> "$out/ktrace.err" || echo "kernel trace failed"
+find "$out/ktrace" -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$out/kernel_stats.csv"
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_TRANS GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_THREAD_CYCLES_VALU" \
+           "SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SENDMSG SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $set -d "$out/pmc$i" --output-format csv -- python3 bench.py $common > "$out/pmc$i.json" 2> "$out/pmc$i.err" || echo "pmc pass $i failed"
+done
+[ -x build/issue_rate ] && timeout -k 10 120 build/issue_rate > "$out/issue_rate.json" 2> "$out/issue_rate.err"
+python3 tools/r03_profiles_summary.py "$cfg" "$out"
