@@ -167,6 +167,8 @@ def issue_model(iss, kern_ms):
     cyc = iss["cycles"]
     per_simd = {k: iss["insts"][k] / simds for k in iss["insts"]}
     t_pipe = {k: per_simd[k] * cyc["pipe"][k] / clk * 1e3 for k in per_simd if k in cyc["pipe"]}
+    if iss.get("lds_pipe_cycles_per_cu"):                 # the LDS pipe's own busy counter (SQ_LDS_IDX_ACTIVE), per CU
+        t_pipe["lds_pipe_busy_counter"] = iss["lds_pipe_cycles_per_cu"] / clk * 1e3
     t_issue = sum(per_simd[k] * cyc["wave"][k] for k in per_simd if k in cyc["wave"]) / iss["waves_per_simd"] / clk * 1e3
     bound = max(max(t_pipe.values()), t_issue)
     return {"bound": "instruction issue", "unit": "ms", "achieved": kern_ms, "peak": bound, "frac": bound / kern_ms,

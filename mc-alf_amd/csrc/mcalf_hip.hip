@@ -242,7 +242,9 @@ __device__ inline void build_line_record(double* rec, double logN, double z, dou
     const float du = (float)(rec[0] * dnu_seg);
     const float du2 = du * du, du4 = du2 * du2;
     const float q = (float)(kInterpC / kInterpTol) * (float)rec[5] * du4 * du4;
-    double uthr = (double)__powf(fmaxf(q, 1.0f), 0.1f) * 1.02;                 // 2 % margin over the float estimate
+    // q^0.1 as exp2(0.1 log2 q) on the hardware's v_log_f32 / v_exp_f32 (q >= 1, so no denormal case; their ~1e-7
+    // relative error is nothing against the margin) -- powf() expands to ~150 instructions of this kernel's serial path
+    double uthr = (double)__builtin_amdgcn_exp2f(0.1f * __builtin_amdgcn_logf(fmaxf(q, 1.0f))) * 1.02;   // 2 % margin over the float estimate
     uthr = fmax(uthr, (double)__fsqrt_rn((float)rec[2]) * 1.000001);           // never inside the core table's range (x2c in [36, 64])
     rec[7] = !(uthr < 1e30) ? INFINITY : uthr;
     if (flag != 0.0) {
@@ -672,12 +674,17 @@ __device__ __forceinline__ void request_item(const KArgs& a, int w, int tid, Ite
     }
     const int t0 = tileIdx * a.tile;
     const int ext0 = selfHalo ? 0 : t0 - a.n_cap;
+    // (the pixel count passes through an empty asm: the reciprocal the wrap's `%` needs is then formed here, per
+    // item, instead of being hoisted out of the item loop and held -- spilled, in the multi-tile instantiations --
+    // through the component loop)
+    int npixW = a.npix;
+    asm volatile("" : "+s"(npixW));
 #pragma unroll
     for (int j = 0; j < kPpt; ++j) {
         int e = ext0 + tid + j * kBlock;
         if (!selfHalo && (e < 0 || e >= a.npix)) {          // (self-halo: nu is padded to the thread count)
             if (kZeroPad) e = 0;                             // jnp.convolve 'same' zero padding (:674)
-            else { e %= a.npix; if (e < 0) e += a.npix; }    // astropy boundary='wrap'
+            else { e %= npixW; if (e < 0) e += npixW; }      // astropy boundary='wrap'
         }
         L.nu[j] = a.nu[e];
     }
@@ -686,7 +693,7 @@ __device__ __forceinline__ void request_item(const KArgs& a, int w, int tid, Ite
     if (kFarInterp) {
         const int wv = tid >> 6, ln = tid & 63;
         int e = ext0 + 64 * wv + kBlock * (ln >> 3) + VT_INTERP_NODES[ln & 7];
-        if (!selfHalo && (e < 0 || e >= a.npix)) { e %= a.npix; if (e < 0) e += a.npix; }   // such segments are never interpolated
+        if (!selfHalo && (e < 0 || e >= a.npix)) { e %= npixW; if (e < 0) e += npixW; }   // such segments are never interpolated
         L.nuNode = a.nu[e];
         L.tileMask = a.segok[tileIdx];                                         // bit m = segment m = wave + 8 j
     }

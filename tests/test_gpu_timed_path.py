@@ -143,6 +143,7 @@ def test_one_launch_variant_of_small_calls_gives_the_two_kernel_bits(cfg, conv, 
     kw = dict(kw, conv_mode=conv)
     rng = np.random.default_rng(seed + 321)
     P = workloads.draw_P(kw, 9, rng, damped=2 if cfg == "E" else 0)
+    cubes = rng.random((5, P.shape[1]))
     out = {}
     for inline_max in ("0", None):
         if inline_max is None:
@@ -160,7 +161,6 @@ def test_one_launch_variant_of_small_calls_gives_the_two_kernel_bits(cfg, conv, 
             res.append(fit.model_batch(P[:2], targonly=True))
             res.append(fit.onecomp_batch(np.array([[8.0, 1.0, 13.5, P[0][fit.startind + 2], 20.0]]), line=0))
             res.append(fit.onecomp_batch(np.array([[7.5, 0.97, 13.1, P[0][fit.startind + 2], 12.0]]), fill=True))
-            cubes = rng.random((5, fit.ndim))
             th, ll = fit.loglike_cube_batch(cubes)
             res += [th, ll]
             res.append(np.array([fit.lnlhood_pc(P[3])[0], fit.lnlhood_dy(P[4])]))

@@ -41,7 +41,7 @@ __global__ void k(double* out, unsigned long long* clk, int iters) {
             for (int r = 0; r < kPerIter / 8; ++r)
                 asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n"
                              "s_add_u32 %4, %4, 1\n s_add_u32 %5, %5, 1\n s_add_u32 %6, %6, 1\n s_add_u32 %7, %7, 1"
-                             : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7));
+                             : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) : : "scc");
         } else if (MODE == 3) {
 #pragma unroll
             for (int r = 0; r < kPerIter / 8; ++r) {
@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
     double* dout; unsigned long long* dclk;
     hipMalloc(&dout, 8 << 20); hipMalloc(&dclk, 1 << 20);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const int iters = 4000;
+    const int iters = 20000;
     const char* nm[5] = {"valu_f64", "valu_other", "salu", "lds", "branch"};
     printf("{\n");
     for (int wi = 0; wi < 2; ++wi) {
@@ -89,14 +89,17 @@ int main(int argc, char** argv) {
                 hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
             }
             unsigned long long h[2]; hipMemcpy(h, dclk, 16, hipMemcpyDeviceToHost);
-            const double ghz = (double)h[0] / ((double)h[1] * 10.0);          // s_memrealtime runs at 100 MHz
-            // cycles the wave spent per loop iteration, from its own clock; with wps waves per SIMD the SIMD issued
-            // wps * kPerIter instructions of the class in that time
-            const double cyc_iter = (double)h[0] / iters;
-            double per_instr = cyc_iter / kPerIter;                            // wave view
-            if (m == 3) per_instr = (cyc_iter - 4.0 * (kPerIter / 8) * 4.0) / kPerIter;   // minus the 4 VALU adds per 8 reads
-            const double simd_view = per_instr / wps;
-            printf("%s\"%s\": %.3f", m ? ", " : "", nm[m], wps == 1 ? per_instr : simd_view);
+            // clock held during the f64 run (s_memtime / s_memrealtime, the latter at 100 MHz); reused for the scalar
+            // classes, whose s_memtime stamps are not ordered with the scalar ALU stream
+            static double ghz = 2.4;
+            if (m == 0) ghz = (double)h[0] / ((double)h[1] * 10.0);
+            // SIMD time per wave-instruction from the kernel's duration (HIP events): with `wps` waves per SIMD the
+            // SIMD issued wps * iters * kPerIter instructions of the class; at wps = 1 this is the issue interval of a wave
+            const double per_simd_instr = (double)wps * iters * kPerIter;
+            double per_instr = (double)ms * 1e-3 * ghz * 1e9 / per_simd_instr;
+            if (m == 3) per_instr -= 0.5 * 4.4;                                      // half a VALU add rides on every read
+            const double simd_view = per_instr;
+            printf("%s\"%s\": %.3f", m ? ", " : "", nm[m], simd_view);
             if (m == 4) printf(", \"clock_ghz\": %.3f", ghz);
         }
         printf("}%s\n", wi == 0 ? "," : "");

@@ -57,6 +57,7 @@ if rate and f64 is not None and g("SQ_INSTS_VALU") and g("SQ_INSTS_LDS") is not 
     clock = rate["pipe"].pop("clock_ghz")
     rate["wave"].pop("clock_ghz", None)
     res["issue"] = {"insts": insts, "simds": 1024, "waves_per_simd": 4, "clock_mhz": clock * 1e3, "cycles": rate,
+                    "lds_pipe_cycles_per_cu": (g("SQ_LDS_IDX_ACTIVE") / 256.0) if g("SQ_LDS_IDX_ACTIVE") else None,
                     "note": "SQ_INSTS_* are wave-instructions summed over the chip; SALU includes scalar memory; the SALU count "
                             "already contains the branches (they are listed, not added twice: branch cycles price the taken-"
                             "branch overhead per branch instruction)",
