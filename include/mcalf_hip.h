@@ -218,11 +218,12 @@ int mcalf_loglike_cube_batch_device(mcalf_ctx* ctx, const double* dcube, int64_t
  * block r at offset counts[0] + ... + counts[r-1].  `counts` is a HOST array [nranks] that every rank passes
  * identically (ragged shards allowed, zeros allowed; counts[rank] must equal batch_local); NULL means every rank
  * evaluates batch_local rows (mcalf_loglike_gather_device is that form).  dlogL_all may be NULL on the other ranks.
- * The exchange runs on a context-owned stream behind an event of `stream`, so the root's NEXT kernels never wait for
- * its peers.  By default the call ends with `stream` waiting for the exchange (plain stream semantics: what follows
- * on `stream` sees the gathered vector).  With mcalf_comm_set_overlap(ctx, 1) it does not: the exchange of call k
- * overlaps the kernels of call k+1, the caller alternates between TWO (dlogL_local, dlogL_all) buffer pairs -- the
- * library orders call k+2 behind exchange k -- and calls mcalf_comm_join(ctx, stream) before it consumes a result.
+ * By default the exchange is enqueued on `stream` itself, right behind the kernels (plain stream semantics: what
+ * follows on `stream` sees the gathered vector; nothing crosses streams).  With mcalf_comm_set_overlap(ctx, 1) and more
+ * than one rank it runs on a context-owned stream behind an event of `stream`, so that the root's NEXT kernels do not
+ * queue behind receives that wait for its peers: the exchange of call k overlaps the kernels of call k+1, the caller
+ * alternates between TWO (dlogL_local, dlogL_all) buffer pairs -- the library orders call k+2 behind exchange k -- and
+ * calls mcalf_comm_join(ctx, stream) before it consumes a result.
  * Nothing synchronises the host.  Because a live point's arithmetic does not depend on the shard, the gathered
  * vector equals the single-GPU result bit for bit.
  *

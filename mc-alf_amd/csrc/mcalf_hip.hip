@@ -2199,14 +2199,19 @@ extern "C" int mcalf_loglike_gatherv_device(mcalf_ctx* ctx, const double* dP, in
     // of NaNs, and reports its error afterwards: the peers' sends / receives complete and the root sees which rows
     // are missing, instead of waiting in ncclRecv for a send that never comes.
     int rc_local = launch_preflight(ctx, kModeLogL, batch_local);
-    if (nranks > 1 || ctx->comm_overlap) {
+    // The exchange runs on the launch stream itself by default (nothing crosses streams: the call has plain stream
+    // semantics for free) and, in overlap mode with more than one rank, on the context's exchange stream behind an
+    // event of the launch stream, so that the root's NEXT kernels do not queue behind receives that wait for its
+    // peers.  (The event traffic of that mode costs about 20 us of queue time per step, measured on one GPU.)
+    const bool side = nranks > 1 && ctx->comm_overlap;
+    if (side) {
         const int rs = comm_ensure_streams(ctx);
         if (rs != MCALF_OK) return comm_fail(ctx, "creating the exchange stream / events", ncclSystemError);
     }
     const unsigned slot = ctx->comm_calls & 1u;
     // the exchange that used this slot two calls ago read the caller's buffers of that call: it must have
     // landed before this call's kernels overwrite them (a caller in overlap mode alternates two buffer pairs)
-    if (ctx->ev_comm_used[slot]) {
+    if (side && ctx->ev_comm_used[slot]) {
         if (hipStreamWaitEvent(st, ctx->ev_comm[slot], 0) != hipSuccess)
             return comm_fail(ctx, "hipStreamWaitEvent", ncclSystemError);
     }
@@ -2215,37 +2220,31 @@ extern "C" int mcalf_loglike_gatherv_device(mcalf_ctx* ctx, const double* dP, in
     const std::string local_msg = ctx->err;
     if (rc_local != MCALF_OK && n > 0) (void)hipMemsetAsync(dlogL_local, 0xFF, n * sizeof(double), st);   // NaN block
     // ---- 4. exchange -----------------------------------------------------------------------------------------
-    if (nranks == 1 && !ctx->comm_overlap) {
-        // one rank: the "gather" is a device-to-device copy behind the kernels
-        if (n > 0 && hipMemcpyAsync(dlogL_all, dlogL_local, n * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    hipStream_t cs = side ? ctx->comm_stream : st;
+    if (side && (hipEventRecord(ctx->ev_kernels, st) != hipSuccess || hipStreamWaitEvent(cs, ctx->ev_kernels, 0) != hipSuccess))
+        return comm_fail(ctx, "hipEventRecord / hipStreamWaitEvent", ncclSystemError);
+    if (is_root) {
+        // (one rank: the "gather" is this device-to-device copy behind the kernels)
+        if (n > 0 && hipMemcpyAsync(dlogL_all + my_off, dlogL_local, n * sizeof(double), hipMemcpyDeviceToDevice, cs) != hipSuccess)
             return comm_fail(ctx, "hipMemcpyAsync", ncclSystemError);
-    } else {
-        hipStream_t cs = ctx->comm_stream;
-        if (hipEventRecord(ctx->ev_kernels, st) != hipSuccess || hipStreamWaitEvent(cs, ctx->ev_kernels, 0) != hipSuccess)
-            return comm_fail(ctx, "hipEventRecord / hipStreamWaitEvent", ncclSystemError);
-        if (is_root) {
-            if (n > 0 && hipMemcpyAsync(dlogL_all + my_off, dlogL_local, n * sizeof(double), hipMemcpyDeviceToDevice, cs) != hipSuccess)
-                return comm_fail(ctx, "hipMemcpyAsync", ncclSystemError);
-            if (nranks > 1) {
-                ncclResult_t e = g_rccl.GroupStart();
-                int64_t off = 0;
-                for (int r = 0; r < nranks && e == ncclSuccess; ++r) {
-                    const int64_t c = counts ? counts[r] : batch_local;
-                    if (r != root && c > 0) e = g_rccl.Recv(dlogL_all + off, (size_t)c, ncclFloat64, r, ctx->comm, cs);
-                    off += c;
-                }
-                const ncclResult_t e2 = g_rccl.GroupEnd();
-                if (e != ncclSuccess || e2 != ncclSuccess) return comm_fail(ctx, "ncclRecv group", e != ncclSuccess ? e : e2);
+        if (nranks > 1) {
+            ncclResult_t e = g_rccl.GroupStart();
+            int64_t off = 0;
+            for (int r = 0; r < nranks && e == ncclSuccess; ++r) {
+                const int64_t c = counts ? counts[r] : batch_local;
+                if (r != root && c > 0) e = g_rccl.Recv(dlogL_all + off, (size_t)c, ncclFloat64, r, ctx->comm, cs);
+                off += c;
             }
-        } else if (n > 0) {
-            const ncclResult_t e = g_rccl.Send(dlogL_local, n, ncclFloat64, root, ctx->comm, cs);
-            if (e != ncclSuccess) return comm_fail(ctx, "ncclSend", e);
+            const ncclResult_t e2 = g_rccl.GroupEnd();
+            if (e != ncclSuccess || e2 != ncclSuccess) return comm_fail(ctx, "ncclRecv group", e != ncclSuccess ? e : e2);
         }
+    } else if (n > 0) {
+        const ncclResult_t e = g_rccl.Send(dlogL_local, n, ncclFloat64, root, ctx->comm, cs);
+        if (e != ncclSuccess) return comm_fail(ctx, "ncclSend", e);
+    }
+    if (side) {
         if (hipEventRecord(ctx->ev_comm[slot], cs) != hipSuccess) return comm_fail(ctx, "hipEventRecord", ncclSystemError);
         ctx->ev_comm_used[slot] = true;
-        // default: plain stream semantics -- whatever follows on `stream` sees the gathered vector
-        if (!ctx->comm_overlap && hipStreamWaitEvent(st, ctx->ev_comm[slot], 0) != hipSuccess)
-            return comm_fail(ctx, "hipStreamWaitEvent", ncclSystemError);
     }
     ctx->comm_calls++;
     if (rc_local != MCALF_OK) {

@@ -38,3 +38,39 @@ def test_profile_json_lookup_tolerates_missing_files():
     assert bench.load_profile_json("does_not_exist.json", "C") is None
     got = bench.load_profile_json("pmc.json", "C")
     assert got is None or 0.0 < got["valu_busy"] < 1.0
+
+
+def test_pmc_figures_are_only_quoted_for_the_kernel_they_were_measured_on():
+    """bench.py drops `traffic` / `valu_busy` / the issue model when the loaded library's kernel-source hash differs
+    from the stamp of the profiles/ record (a kernel edit must not ship stale utilisation numbers)."""
+    entry = {"source_hash": "abc", "valu_busy": 0.6}
+    assert bench.stamped(entry, "abc") == (entry, None)
+    got, why = bench.stamped(entry, "def")
+    assert got is None and "abc" in why and "def" in why
+    assert bench.stamped({"valu_busy": 0.6}, "abc")[0] is None            # an unstamped (round-2) record
+    assert bench.stamped(entry, "unstamped")[0] is None                   # a library built outside mc-alf_amd/build.py
+    assert bench.stamped(None, "abc")[0] is None
+
+
+def test_library_carries_the_hash_of_the_device_sources():
+    import importlib
+    import mcalf_amd
+    bld = importlib.import_module("mc-alf_amd.build")
+    lib = mcalf_amd._lib.load()
+    assert bench.library_source_hash(lib) == bld.source_hash()            # built by __graft_entry__.build()
+    # the hash covers the device part of mcalf_hip.hip only: the host-section marker must exist exactly once
+    src = open(os.path.join(bld.CSRC, "mcalf_hip.hip"), "rb").read()
+    assert src.count(bld.HOST_MARKER) == 1
+
+
+def test_issue_model_arithmetic():
+    iss = {"insts": {"valu_f64": 4.0e6, "salu": 2.0e6}, "simds": 1000, "waves_per_simd": 4, "clock_mhz": 2000.0,
+           "cycles": {"wave": {"valu_f64": 5.0, "salu": 4.0}, "pipe": {"valu_f64": 4.0, "salu": 4.0}},
+           "lds_pipe_cycles_per_cu": 10000.0}
+    out = bench.issue_model(iss, kern_ms=0.02)
+    # pipes: valu 4000 wave-instructions per SIMD x 4 cycles = 16000 cycles = 0.008 ms; salu 2000 x 4 = 0.004 ms
+    assert abs(out["pipe_ms"]["valu_f64"] - 0.008) < 1e-12 and abs(out["pipe_ms"]["salu"] - 0.004) < 1e-12
+    assert abs(out["pipe_ms"]["lds_pipe_busy_counter"] - 0.005) < 1e-12
+    # serial issue: (4000 x 5 + 2000 x 4) / 4 waves = 7000 cycles = 0.0035 ms
+    assert abs(out["serial_issue_ms"] - 0.0035) < 1e-12
+    assert abs(out["peak"] - 0.008) < 1e-12 and abs(out["frac"] - 0.4) < 1e-12
