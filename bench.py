@@ -166,16 +166,23 @@ def issue_model(iss, kern_ms):
     clk = iss["clock_mhz"] * 1e6
     cyc = iss["cycles"]
     per_simd = {k: iss["insts"][k] / simds for k in iss["insts"]}
-    t_pipe = {k: per_simd[k] * cyc["pipe"][k] / clk * 1e3 for k in per_simd if k in cyc["pipe"]}
-    if iss.get("lds_pipe_cycles_per_cu"):                 # the LDS pipe's own busy counter (SQ_LDS_IDX_ACTIVE), per CU
-        t_pipe["lds_pipe_busy_counter"] = iss["lds_pipe_cycles_per_cu"] / clk * 1e3
+    t_class = {k: per_simd[k] * cyc["pipe"][k] / clk * 1e3 for k in per_simd if k in cyc["pipe"]}
+    # classes that share a pipe add up: both VALU classes issue on the SIMD's vector pipe, SALU and branches on the
+    # scalar pipe; the LDS pipe is priced by its own busy counter (SQ_LDS_IDX_ACTIVE, per CU) when there is one
+    t_pipe = {"valu": t_class.get("valu_f64", 0.0) + t_class.get("valu_other", 0.0),
+              "scalar": t_class.get("salu", 0.0) + t_class.get("branch", 0.0),
+              "lds": t_class.get("lds", 0.0)}
+    if iss.get("lds_pipe_cycles_per_cu"):
+        t_pipe["lds"] = iss["lds_pipe_cycles_per_cu"] / clk * 1e3
     t_issue = sum(per_simd[k] * cyc["wave"][k] for k in per_simd if k in cyc["wave"]) / iss["waves_per_simd"] / clk * 1e3
     bound = max(max(t_pipe.values()), t_issue)
     return {"bound": "instruction issue", "unit": "ms", "achieved": kern_ms, "peak": bound, "frac": bound / kern_ms,
-            "pipe_ms": t_pipe, "serial_issue_ms": t_issue, "waves_per_simd": iss["waves_per_simd"],
+            "pipe_ms": t_pipe, "class_ms": t_class, "busiest_pipe": max(t_pipe, key=t_pipe.get),
+            "serial_issue_ms": t_issue, "waves_per_simd": iss["waves_per_simd"],
             "wave_instructions_per_launch": iss["insts"], "cycles_per_instruction": cyc,
-            "note": "frac = the time the measured instruction stream needs at the measured issue rates over the kernel's "
-                    "duration: near 1 means only removing instructions makes the kernel faster"}
+            "note": "frac = the time the busiest pipe (or one wave's serial issue, shared by the SIMD's waves) needs for the "
+                    "MEASURED instruction stream at the MEASURED issue rates, over the kernel's duration; 1 - frac is time no "
+                    "pipe limit explains: dependency and LDS-latency stalls that four waves per SIMD do not cover"}
 
 
 def main():

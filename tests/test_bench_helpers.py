@@ -69,8 +69,9 @@ def test_issue_model_arithmetic():
            "lds_pipe_cycles_per_cu": 10000.0}
     out = bench.issue_model(iss, kern_ms=0.02)
     # pipes: valu 4000 wave-instructions per SIMD x 4 cycles = 16000 cycles = 0.008 ms; salu 2000 x 4 = 0.004 ms
-    assert abs(out["pipe_ms"]["valu_f64"] - 0.008) < 1e-12 and abs(out["pipe_ms"]["salu"] - 0.004) < 1e-12
-    assert abs(out["pipe_ms"]["lds_pipe_busy_counter"] - 0.005) < 1e-12
+    assert abs(out["class_ms"]["valu_f64"] - 0.008) < 1e-12 and abs(out["class_ms"]["salu"] - 0.004) < 1e-12
+    assert abs(out["pipe_ms"]["valu"] - 0.008) < 1e-12 and abs(out["pipe_ms"]["scalar"] - 0.004) < 1e-12
+    assert abs(out["pipe_ms"]["lds"] - 0.005) < 1e-12 and out["busiest_pipe"] == "valu"
     # serial issue: (4000 x 5 + 2000 x 4) / 4 waves = 7000 cycles = 0.0035 ms
     assert abs(out["serial_issue_ms"] - 0.0035) < 1e-12
     assert abs(out["peak"] - 0.008) < 1e-12 and abs(out["frac"] - 0.4) < 1e-12
