@@ -174,3 +174,38 @@ def test_one_launch_variant_of_small_calls_gives_the_two_kernel_bits(cfg, conv, 
         got = fit.loglike_batch(big)
         assert fit.last_launch().inline_setup == 0
     assert np.array_equal(got[:9], out[None][2])
+
+
+def test_model_output_entry_on_the_persistent_grid_against_the_oracle():
+    """`mcalf_model_batch_device` as bench.py's model-output leg drives it -- one persistent launch, the plain
+    model-output epilogue -- against the oracle's reconstruct_spec on a spread of rows, and bit-equal to the same
+    rows evaluated one at a time (the one-launch variant): hires_fitter.py:409-449, consumer cli.py:414-418."""
+    kw, _, seed = workloads.config("C", oracle_synth)
+    n = 2600
+    P = workloads.draw_P(kw, n, np.random.default_rng(seed + 55))
+    prob = problem_from_kwargs(kw)
+    dP = torch.from_numpy(P).cuda()
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        npix = fit.obj_wl.size
+        flux = torch.full((n, npix), float("nan"), dtype=torch.float64, device="cuda")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for targonly in (0, 1):
+            _lib.check(fit._lib.mcalf_model_batch_device(fit._ctx, dP.data_ptr(), n, targonly, flux.data_ptr(), st), fit._ctx)
+            torch.cuda.synchronize()
+            ll = fit.last_launch()
+            assert ll.path == _lib.MCALF_PATH_DEVICE and ll.persistent == 1 and ll.items == n and ll.inline_setup == 0
+            got = flux.cpu().numpy()
+            assert np.isfinite(got).all()
+            for i in range(0, n, 325):
+                ref = o.reconstruct_spec(prob, P[i], targonly=bool(targonly))
+                assert np.abs(got[i] - ref).max() < 1e-11 and np.abs(got[i] / ref - 1).max() < 1e-6
+                one = fit.model_batch(P[i:i + 1], targonly=bool(targonly))[0]
+                assert fit.last_launch().inline_setup == 1
+                assert np.array_equal(one, got[i])
+        # logL recomputed on the host from the device's model spectra = the log-likelihood entry (hires_fitter.py:292-294)
+        _lib.check(fit._lib.mcalf_model_batch_device(fit._ctx, dP.data_ptr(), n, 0, flux.data_ptr(), st), fit._ctx)
+        torch.cuda.synchronize()
+        m = flux.cpu().numpy()[:64]
+        ispec2 = 1.0 / fit.obj_noise ** 2
+        ll_host = -0.5 * np.nansum(ispec2 * (fit.obj - m) ** 2 - np.log(ispec2) + np.log(2 * np.pi), axis=1)
+        assert np.abs(ll_host - _device_logl(fit, dP, n)[:64]).max() < 1e-6
