@@ -209,3 +209,38 @@ def test_model_output_entry_on_the_persistent_grid_against_the_oracle():
         ispec2 = 1.0 / fit.obj_noise ** 2
         ll_host = -0.5 * np.nansum(ispec2 * (fit.obj - m) ** 2 - np.log(ispec2) + np.log(2 * np.pi), axis=1)
         assert np.abs(ll_host - _device_logl(fit, dP, n)[:64]).max() < 1e-6
+
+
+def test_ordered_persistent_row_blocks_and_graph_replay():
+    """Row blocks that are each large enough for the persistent grid get their own queue and their own hand-out
+    order (block-local indices); a captured persistent launch replays correctly (the set-up kernel of every replay
+    resets the queue and rebuilds the order)."""
+    kw, _, seed = workloads.config("C", oracle_synth)
+    n = 4600
+    P = workloads.draw_P(kw, n, np.random.default_rng(seed + 91))
+    dP = torch.from_numpy(P).cuda()
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        _lib.check(fit._lib.mcalf_reserve(fit._ctx, n), fit._ctx)
+        fit.set_chunks(1)
+        whole = _device_logl(fit, dP, n)
+        ll = fit.last_launch()
+        assert ll.persistent == 1 and ll.ordered == 1 and ll.row_blocks == 1
+        fit.set_chunks(2)                                        # 2 x 2300 rows: both blocks persistent and ordered
+        for _ in range(2):
+            assert np.array_equal(_device_logl(fit, dP, n), whole)
+        ll = fit.last_launch()
+        assert ll.row_blocks == 2 and ll.persistent == 1 and ll.ordered == 1 and ll.items == 2300
+        fit.set_chunks(1)
+        out = torch.zeros(n, dtype=torch.float64, device="cuda")
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                _lib.check(fit._lib.mcalf_loglike_batch_device(fit._ctx, dP.data_ptr(), n, out.data_ptr(), st), fit._ctx)
+        for _ in range(3):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), whole)
