@@ -28,9 +28,9 @@ def rep(a, b):
     s = s.replace(a, b, 1)
 
 
-rep("template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync>\n__global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {",
+rep("template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync, bool kInline>\n__global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {",
     "__device__ unsigned long long g_acc[8192 * 32];\n#define CLK() __builtin_amdgcn_s_memtime()\n"
-    "template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync>\n__global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {\n"
+    "template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync, bool kInline>\n__global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {\n"
     "    unsigned long long accFold = 0, accBar = 0, accNode = 0, accDirect = 0;")
 rep("                                          double& farNode, unsigned long long segOk) {\n    const double A = tab[kLineLds + 1], B = tab[kLineLds + 2];",
     "                                          double& farNode, unsigned long long segOk, unsigned long long& accNode, unsigned long long& accDirect) {\n"
