@@ -244,3 +244,24 @@ def test_ordered_persistent_row_blocks_and_graph_replay():
             g.replay()
             torch.cuda.synchronize()
             assert np.array_equal(out.cpu().numpy(), whole)
+
+
+@pytest.mark.parametrize("block", ["64", "192", "512"])
+def test_set_up_geometry_and_chunked_ordering_do_not_change_results(block, monkeypatch):
+    """MCALF_SETUP_BLOCK: the set-up kernel's workgroup size (one wave per live point) and with it the number of
+    keys the ordering workgroup holds at a time -- with 64 threads it sorts 4096 live points in four chunks and
+    reloads its keys for the second pass.  Scheduling only."""
+    kw, _, seed = workloads.config("C", oracle_synth)
+    n = 4096
+    P = workloads.draw_P(kw, n, np.random.default_rng(seed + 7))
+    dP = torch.from_numpy(P).cuda()
+    monkeypatch.delenv("MCALF_SETUP_BLOCK", raising=False)
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        ref = _device_logl(fit, dP, n)
+    monkeypatch.setenv("MCALF_SETUP_BLOCK", block)
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        got = _device_logl(fit, dP, n)
+        assert fit.last_launch().ordered == 1 and fit.last_launch().persistent == 1
+        small = fit.loglike_batch(P[:700])                       # two-kernel path, not persistent
+        assert fit.last_launch().persistent == 0 and fit.last_launch().inline_setup == 0
+    assert np.array_equal(got, ref) and np.array_equal(small, ref[:700])
