@@ -40,7 +40,8 @@
 extern "C" {
 #endif
 
-#define MCALF_ABI_VERSION 2   /* 2: mcalf_last_launch, gatherv / overlap / join, version string carries the source hash */
+#define MCALF_ABI_VERSION 3   /* 2: mcalf_last_launch, gatherv / overlap / join, version string carries the source hash
+                                 3: MCALF_PATH_HOST_STREAM, mcalf_launch_info_t grows by stream_setup_wgs / stream_polled */
 
 enum {
     MCALF_OK = 0,
@@ -137,9 +138,10 @@ int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batch, int32_t 
 
 /* Row blocks a batch is issued in (0 = automatic [default], n <= 8 = exactly n).  Automatic means ONE block
  * for the *_device entries (the persistent fused kernel leaves no launch tail worth filling; measured) and, for
- * the host-pointer entries with large batches, a small first block followed by larger ones (1:1:2:4 of the rows
- * for pageable input, 1:7 for page-locked input), so that block k+1's H2D copy and per-sample set-up run under
- * block k's kernel and block k's D2H copy under block k+1's.  With more than one block in a *_device call the
+ * the host-pointer entries with large batches, ONE streaming launch (MCALF_PATH_HOST_STREAM; an explicit block count,
+ * MCALF_STREAM=0 or a launch below the persistent-grid threshold selects the row-block pipeline instead: a small first
+ * block followed by larger ones, 1:1:2:4 of the rows for pageable input, 1:7 for page-locked input, so that block k+1's
+ * H2D copy and per-sample set-up run under block k's kernel).  With more than one block in a *_device call the
  * blocks after the first run on context-owned streams between a fork event recorded on the caller's stream and
  * join events that stream waits for: the call keeps plain stream semantics (and can be captured into a
  * hipGraph).  Results do not depend on the setting (every live point is evaluated independently).  The
@@ -165,7 +167,10 @@ enum {
     MCALF_PATH_DEVICE = 1,        /* a *_device entry (caller's device pointers and stream)                   */
     MCALF_PATH_HOST_ZEROCOPY = 2, /* host pointers, small call: theta / logL through the page-locked mapped block */
     MCALF_PATH_HOST_PIPELINED = 3,/* host pointers, large scalar-output call: row blocks over two streams     */
-    MCALF_PATH_HOST_STAGED = 4    /* host pointers, model output: H2D, launch, D2H on the context's stream    */
+    MCALF_PATH_HOST_STAGED = 4,   /* host pointers, model output: H2D, launch, D2H on the context's stream    */
+    MCALF_PATH_HOST_STREAM = 5    /* host pointers, large scalar-output call: ONE streaming launch, no copy commands --
+                                     the grid reads the parameter rows from page-locked memory while the host is still
+                                     staging them, sets the live points up itself and writes logL into page-locked memory */
 };
 typedef struct {
     int32_t path;           /* MCALF_PATH_*                                                                   */
@@ -179,6 +184,8 @@ typedef struct {
     int32_t pinned_out;     /* host-pointer entries: the result array was page-locked caller memory           */
     int32_t inline_setup;   /* 1: small launch -- ONE kernel, the per-sample set-up ran inside the fused kernel */
     int32_t ordered;        /* 1: the persistent grid handed the live points out sorted by component count      */
+    int32_t stream_setup_wgs; /* MCALF_PATH_HOST_STREAM: workgroups of the grid dedicated to the set-up while rows were outstanding */
+    int32_t stream_polled;  /* MCALF_PATH_HOST_STREAM: 1 = completion seen through the kernel's page-locked word, 0 = stream signal */
 } mcalf_launch_info_t;
 int mcalf_last_launch(const mcalf_ctx* ctx, mcalf_launch_info_t* info);
 

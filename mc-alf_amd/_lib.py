@@ -66,7 +66,8 @@ class mcalf_info_t(C.Structure):
     ]
 
 
-MCALF_PATH_NONE, MCALF_PATH_DEVICE, MCALF_PATH_HOST_ZEROCOPY, MCALF_PATH_HOST_PIPELINED, MCALF_PATH_HOST_STAGED = range(5)
+(MCALF_PATH_NONE, MCALF_PATH_DEVICE, MCALF_PATH_HOST_ZEROCOPY, MCALF_PATH_HOST_PIPELINED, MCALF_PATH_HOST_STAGED,
+ MCALF_PATH_HOST_STREAM) = range(6)
 
 
 class mcalf_launch_info_t(C.Structure):
@@ -82,6 +83,8 @@ class mcalf_launch_info_t(C.Structure):
         ("pinned_out", C.c_int32),
         ("inline_setup", C.c_int32),
         ("ordered", C.c_int32),
+        ("stream_setup_wgs", C.c_int32),
+        ("stream_polled", C.c_int32),
     ]
 
 
@@ -97,7 +100,8 @@ SYMBOLS = {
     "mcalf_reserve": (C.c_int, [_CTX, C.c_int64]),
     "mcalf_set_chunks": (C.c_int, [_CTX, C.c_int32]),
     "mcalf_get_chunks": (C.c_int32, [_CTX, C.c_int64]),
-    "mcalf_loglike_batch": (C.c_int, [_CTX, _PD, C.c_int64, _PD]),
+    # (host pointers as void*: plain addresses are accepted, which spares the hot wrappers two ctypes pointer objects per call)
+    "mcalf_loglike_batch": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_void_p]),
     "mcalf_model_batch": (C.c_int, [_CTX, _PD, C.c_int64, C.c_int32, _PD]),
     "mcalf_chi2_batch": (C.c_int, [_CTX, _PD, C.c_int64, _PD]),
     "mcalf_onecomp_batch": (C.c_int, [_CTX, _PD, C.c_int64, C.c_int32, _PD]),

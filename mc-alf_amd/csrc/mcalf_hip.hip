@@ -23,6 +23,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -125,7 +127,46 @@ struct KArgs {
     // order[t] -- the live points sorted by their component count, longest first (written by one extra workgroup
     // of the set-up kernel); nullptr = ticket order.  Scheduling only: a live point's arithmetic does not depend on who evaluates it when.
     int* order;
+    // Streaming single launch (mcalf_fused_kernel<..., kStream = true>, the host-pointer entries): there is no set-up
+    // kernel and no copy command.  The grid sets the live points up itself -- the first `stream_wgs` workgroups keep
+    // doing so, row after row as the rows arrive, until none is left, and only then join the others at the item queue
+    // -- and a work item is handed to the component loop once its row's stamp says it is set up.
+    struct StreamCtl* sctl; // per-XCD item queues and row queues, exit count (self-resetting: the last workgroup out zeroes them)
+    unsigned int* ready;    // [batch] ready[s] == gen: live point s is set up (records, taps, header in HBM)
+    const unsigned int* arrived;   // rows of P the host has staged so far (page-locked, device-mapped word); nullptr: all
+    unsigned int* status;   // page-locked, device-mapped: [0] != 0: a wait ran out (the call fails), [1] = gen when the grid has drained
+    unsigned int gen;       // stamp of this call
+    int nrows;              // live points of this launch
+    int stream_wgs;         // workgroups PER XCD (the first ones to start there) dedicated to the set-up until the XCD's rows are done
+    int eager_rows;         // local BLOCKS (of 8 rows) per XCD that whichever workgroup of the XCD gets there first sets up (the
+                            // rows the XCD's first items need; all of them when P is resident in HBM)
+    long long spin_ticks;   // longest wait, in ticks of s_memrealtime (100 MHz)
+    double* Pdev;           // [batch][ndim] in HBM: where the workgroups copy rows that live in host memory; nullptr: P is in HBM
+    int rest_chunk;         // rows a dedicated workgroup claims at a time (a multiple of 8: whole blocks)
+    int rec_stride, tap_stride, hdr_stride;   // doubles between the records / taps / headers of consecutive live points in the
+                            // streaming workspaces: multiples of a 128-byte line, so that no two live points share one
 };
+
+constexpr int kXcds = 8;                // XCDs of an MI355X (the streaming launch keeps every hand-over inside one of them)
+struct StreamCtl {                      // per XCD x: its own queues over ITS live points (blocks of 8 rows, block k -> XCD k % 8)
+    unsigned int arrive[kXcds];         // workgroups of the launch that started on XCD x (the first few are its set-up workgroups)
+    unsigned int sq_eager[kXcds];       // local blocks claimed of [0, eager_blocks): any workgroup of the XCD
+    unsigned int sq_rest[kXcds];        // local blocks claimed of the rest: the XCD's dedicated workgroups
+    unsigned int queue[kXcds];          // local tickets handed out by the XCD's item queue
+    unsigned int exited;                // workgroups that have left the kernel
+};
+
+// The XCD a wave runs on (XCC_ID, bits 3:0 of hardware register 20 on gfx942 / gfx950).
+__device__ __forceinline__ int xcd_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & (kXcds - 1)); }
+// Live points of XCD x when the rows are dealt out in blocks of eight (block k -> XCD k % kXcds), and the row behind the
+// XCD's local index j.
+__device__ __forceinline__ int stream_rows_of(int nrows, int x) {
+    const int nblocks = (nrows + 7) >> 3;
+    if (nblocks <= x) return 0;
+    const int nbx = (nblocks - x + kXcds - 1) / kXcds;
+    return 8 * nbx - ((nblocks - 1) % kXcds == x ? 8 * nblocks - nrows : 0);
+}
+__device__ __forceinline__ int stream_row(int x, int j) { return 64 * (j >> 3) + 8 * x + (j & 7); }
 
 // LDS flux tile, "mod-8 planar": element i lives in plane (i & 7) at index (i >> 3).  The convolution
 // thread that owns outputs 8g..8g+7 then reads every plane at consecutive indices with compile-time
@@ -553,7 +594,7 @@ __device__ __forceinline__ void setup_sample(const KArgs& a, long s, int lane, d
     const int ntap8 = (2 * n + 1 + 7) & ~7;
     const double inv2s2 = kZeroPad ? 1.0 / (2.0 * sigma * sigma) : 0.5 / (sigma * sigma);
     const double amp = kZeroPad ? 1.0 : 1.0 / (sqrt(2.0 * M_PI) * sigma);          // Gaussian1DKernel amplitude
-    double wsum = 0.0;
+    double wsum = 0.0, botOrdered = 0.0;
 #if defined(MCALF_ABL_SETUP) && (MCALF_ABL_SETUP & 1)   // ablation builds only (tools/): no taps
     if (false) {
 #else
@@ -564,6 +605,16 @@ __device__ __forceinline__ void setup_sample(const KArgs& a, long s, int lane, d
         const double gsum = wave_allsum(g);
         wsum = g / gsum;
         if (lane < ntap8 && writeTaps) taps[lane] = wsum;
+        // astropy's loop adds the taps up next to the data sum, tap after tap (`bot`), and divides by that: formed
+        // here in the SAME order as the fused kernel's numerator chain (tap 0 first), so that a constant model comes
+        // out of the convolution as exactly that constant, as it does in the reference (hires_fitter.py:463-464)
+        if (!kZeroPad) {
+            const unsigned long long wb = __builtin_bit_cast(unsigned long long, wsum);
+            for (int k = 0; k <= 2 * n; ++k) {
+                const unsigned lo = __builtin_amdgcn_readlane((unsigned)wb, k), hi = __builtin_amdgcn_readlane((unsigned)(wb >> 32), k);
+                botOrdered += __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+            }
+        }
     } else
 #if defined(MCALF_ABL_SETUP) && (MCALF_ABL_SETUP & 1)
     if (false)
@@ -578,15 +629,20 @@ __device__ __forceinline__ void setup_sample(const KArgs& a, long s, int lane, d
         for (int k = lane; k < ntap8; k += 64) {
             const double dk = (double)(k - n);
             const double w = (k <= 2 * n) ? exp_neg((dk * dk) * inv2s2) * amp / gsum : 0.0;   // zero-padded to 8
-            wsum += w;
             if (writeTaps) taps[k] = w;
         }
+        // (more than 64 taps: rare; every lane repeats the tap expression for the tap-ordered sum)
+        if (!kZeroPad)
+            for (int k = 0; k <= 2 * n; ++k) {
+                const double dk = (double)(k - n);
+                botOrdered += exp_neg((dk * dk) * inv2s2) * amp / gsum;
+            }
     }
 #if defined(MCALF_ABL_SETUP) && (MCALF_ABL_SETUP & 1)
     const double bot = 1.0;
     const int ngen = 0;
 #else
-    const double bot = kZeroPad ? 1.0 : wave_allsum(wsum);
+    const double bot = kZeroPad ? 1.0 : botOrdered;
     const int ngen = ngenLane;
 #endif
     if (lane == 0) {
@@ -594,6 +650,63 @@ __device__ __forceinline__ void setup_sample(const KArgs& a, long s, int lane, d
         h.cont = cont; h.bot = bot; h.ncl = ncl; h.n = n; h.bad = bad ? 1 : 0; h.ngeneral = ngen;
         *hdrOut = h;
     }
+}
+
+// ---- streaming single launch: hand-over between waves, waits ---------------------------------------------------------
+// Waves of ONE launch hand data to each other here (records / taps / header of a live point, its stamp, the HBM copy of
+// its parameter row), and the host hands rows to the launch while it runs.  The eight XCDs of an MI355X each have their
+// own L2, which is not coherent with the others' for ordinary device memory: across XCDs a hand-over needs an agent-scope
+// release (write back the producer's L2) and acquire (invalidate the consumer's) -- measured here at 4x the launch's
+// duration when done per row and per item.  So nothing is handed over ACROSS XCDs: the live points are dealt out to the
+// XCDs in blocks of eight rows (block k -> XCD k % 8), every XCD sets up ITS rows with its own workgroups and consumes
+// them with its own workgroups through its own queue (xcd_id(): the hardware's XCC_ID, not an assumption about the
+// dispatch order).  Producer and consumer of a row share one L2, which IS coherent: plain stores, a wait for their
+// acknowledgement (s_waitcnt vmcnt(0): they are in the L2), then the stamp; the consumer sees the stamp and reads the row
+// with plain loads.  Rows own their 128-byte lines, so a consumer's L1 never holds a line of a row it has not been handed.
+// Stamps and queue counters are device-scope atomics, which meet in memory.  The host's rows and words are page-locked
+// coherent memory, read past every cache; RESULTS go to page-locked memory as system-scope stores (write-through), because
+// the host reads them as soon as the completion word says so, ahead of the end-of-kernel write-back -- plain stores were
+// measured to linger in one XCD's L2 past that word (rows of one XCD missing from the first call's results).
+__device__ __forceinline__ void stream_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void stream_compiler_barrier() { asm volatile("" ::: "memory"); }
+
+// Every wait is bounded (a.spin_ticks of the 100 MHz s_memrealtime clock): a wave that runs out of patience raises
+// status[0], after which nobody waits any more -- the rows still missing are published as unusable (`bad`: logL = -inf)
+// and the grid drains; the host sees status[0] and fails the call.  No wave can stay behind in the kernel.
+__device__ __forceinline__ bool stream_gave_up(const KArgs& a) {
+    return __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+}
+
+// Wait until the host has staged row r (a.arrived counts the rows staged so far).  false: gave up.
+__device__ __forceinline__ bool stream_wait_arrived(const KArgs& a, unsigned r, unsigned& seen) {
+    if (seen > r) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (true) {
+        seen = __hip_atomic_load(a.arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        stream_compiler_barrier();                       // (the row's loads are issued behind this one's return)
+        if (seen > r) return true;
+        if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > a.spin_ticks || stream_gave_up(a)) {
+            __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(32);                    // (~1 us: a poll is a PCIe read)
+    }
+}
+
+// Wait until live point s is set up (every lane of the workgroup calls this with the same s).  Its records, taps
+// and header were written by a wave of this XCD, into the L2 both share, before its stamp.
+__device__ __forceinline__ void stream_wait_ready(const KArgs& a, int s, unsigned early) {
+    if (early != a.gen) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(a.ready + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.gen) {
+            if ((long long)(__builtin_amdgcn_s_memrealtime() - t0) > a.spin_ticks) {   // (never seen: the producers' own waits are bounded)
+                __hip_atomic_store(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    stream_compiler_barrier();
 }
 
 template <bool kZeroPad>
@@ -630,6 +743,112 @@ __device__ __forceinline__ void eval_general_lines(const double* __restrict__ sR
     }
 }
 
+// Streaming single launch, set-up phase of a workgroup on XCD x (one WAVE per live point, as in mcalf_sample_kernel; same
+// setup_sample(), same bits).  A workgroup claims local blocks (eight consecutive rows each) of ITS XCD with one atomic --
+// one of the first `eager_rows` blocks, which any workgroup of the XCD may take; then, a dedicated workgroup only (the
+// first `stream_wgs` to start on the XCD), `rest_chunk` / 8 of the remaining ones, in ticket order, until none is left.
+// Thread 0 alone asks the host's row count (every wave polling a word of host memory saturated the PCIe read queue the
+// rows themselves come through).  Rows that live in host memory are first copied to HBM by the whole workgroup --
+// coalesced, all loads of the claim in flight at once, ONE PCIe round trip instead of setup_sample's two or three
+// dependent ones -- and set up from the copy.  Claims are dynamic on purpose: a row is owned by a workgroup that is
+// running, never by one that waits for a slot.
+template <bool kZeroPad>
+__device__ __forceinline__ void stream_setup_phase(const KArgs& a, int tid, int x, int* sClaim) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nloc = stream_rows_of(a.nrows, x), nblk = (nloc + 7) >> 3;      // this XCD's live points / local blocks
+    const int eager = min(a.eager_rows, nblk);
+    KArgs as = a;
+    if (a.Pdev) as.P = a.Pdev;                           // the rows are set up from their copy in HBM
+    unsigned seen = a.arrived ? 0u : (unsigned)a.nrows;  // (thread 0's view of the host's row count)
+    if (tid == 0) sClaim[3] = (int)atomicAdd(&a.sctl->arrive[x], 1u);
+    __syncthreads();
+    const bool dedicated = sClaim[3] < a.stream_wgs;
+    bool rest = false;
+    // A dedicated workgroup shares its CU with a workgroup that is in the component loop at raised priority; the
+    // set-up is a chain of latencies with few instructions: it goes first, and the queue stays ahead of the consumers.
+    __builtin_amdgcn_s_setprio(3);
+    while (true) {
+        if (tid == 0) {
+            const int want = rest ? max(a.rest_chunk >> 3, 1) : 1, lim = rest ? nblk : eager;
+            const int c = rest ? eager + (int)atomicAdd(&a.sctl->sq_rest[x], (unsigned)want) : (int)atomicAdd(&a.sctl->sq_eager[x], 1u);
+            const int cnt = c < lim ? min(want, lim - c) : 0;
+            int ok = 1;
+            if (cnt != 0 && a.arrived) {                 // (rows arrive in order: the claim's last row is the one to wait for)
+                const int last = min(stream_row(x, 8 * (c + cnt) - 1), a.nrows - 1);
+                ok = stream_wait_arrived(a, (unsigned)last, seen) ? 1 : 0;
+            }
+            sClaim[0] = c; sClaim[1] = cnt; sClaim[2] = ok;
+        }
+        __syncthreads();
+        const int c = sClaim[0], cnt = sClaim[1];
+        const bool ok = sClaim[2] != 0;
+        __syncthreads();                                 // (the slots are rewritten by the next claim)
+        if (cnt == 0) {
+            if (!rest && dedicated) { rest = true; continue; }
+            break;
+        }
+        if (a.Pdev && ok) {                              // host -> HBM, block after block (a block's rows are contiguous)
+            const int perBlock = 8 * a.ndim, n = cnt * perBlock;
+            for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {
+                double v[4];
+                size_t at[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + k * kBlock, blk = i / perBlock;
+                    at[k] = (size_t)stream_row(x, 8 * (c + blk)) * a.ndim + (size_t)(i - blk * perBlock);
+                    v[k] = (i < n && at[k] < (size_t)a.nrows * a.ndim) ? a.P[at[k]] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (i0 + k * kBlock < n && at[k] < (size_t)a.nrows * a.ndim) a.Pdev[at[k]] = v[k];
+            }
+            stream_stores_done();
+            __syncthreads();
+        }
+        // the wave's rows of the claim (one per block), one after the other; ONE wait for the L2's acknowledgements, then
+        // their stamps (a wait per row put the stores' round trip on the path of every row)
+        for (int k = 0; k < cnt; ++k) {
+            const int r = stream_row(x, 8 * (c + k) + wave);
+            if (r >= a.nrows) continue;
+            SampleHdr* hdrp = reinterpret_cast<SampleHdr*>(reinterpret_cast<double*>(a.hdr) + (size_t)r * a.hdr_stride);
+            if (ok) {
+                setup_sample<kZeroPad>(as, (long)r, lane, a.recs + (size_t)r * a.rec_stride, a.taps + (size_t)r * a.tap_stride, true, hdrp, true);
+            } else if (lane == 0) {                      // gave up on the host: a row nobody will mistake for a result
+                SampleHdr h;
+                h.cont = 0.0; h.bot = 1.0; h.ncl = 0; h.n = 0; h.bad = 1; h.ngeneral = 0;
+                *hdrp = h;
+            }
+        }
+        stream_stores_done();                            // the rows' records / taps / headers are in the L2 before their stamps
+        if (lane < cnt) {
+            const int r = stream_row(x, 8 * (c + lane) + wave);
+            if (r < a.nrows) __hip_atomic_store(a.ready + r, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+}
+
+// A workgroup of the streaming launch leaves the kernel: the last one out re-arms the queues for the next launch and
+// tells the host (status[1] = gen; every result of every workgroup has been acknowledged by the memory system by
+// then, and results and word travel to the host as posted writes in that order -- the host polls this word instead of
+// waiting for the stream's signal).  Thread 0 wrote the workgroup's results itself.
+__device__ __forceinline__ void stream_exit(const KArgs& a, int tid) {
+    if (tid != 0) return;
+    stream_stores_done();
+    if (atomicAdd(&a.sctl->exited, 1u) == gridDim.x - 1) {
+        for (int k = 0; k < kXcds; ++k) {
+            __hip_atomic_store(&a.sctl->arrive[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.sctl->sq_eager[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.sctl->sq_rest[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.sctl->queue[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_store(&a.sctl->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stream_stores_done();
+        __hip_atomic_store(a.status + 1, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 #ifndef MCALF_MIN_WAVES
 #define MCALF_MIN_WAVES 4
 #endif
@@ -648,7 +867,9 @@ struct ItemLoads {
 // Issue every global load of work item w (one memory round trip; the record and tap copies run to their
 // provisioned sizes, which do not depend on the header: slots beyond the sample's own counts hold stale
 // values that are never read).
-template <bool kZeroPad, bool selfHalo, bool kInline>
+// kCoh: the streaming launch -- header, records and taps of a live point were written by a wave of the SAME launch on the
+// same XCD, into rows of their own 128-byte lines (a.hdr_stride / rec_stride / tap_stride); see stream_setup_phase.
+template <bool kZeroPad, bool selfHalo, bool kInline, bool kCoh = false>
 __device__ __forceinline__ void request_item(const KArgs& a, int w, int tid, ItemLoads& L) {
     // The thread index is laundered through an empty asm so that the (item-invariant) load addresses are formed
     // here, from one register, instead of being hoisted out of the item loop and kept alive -- ~30 registers --
@@ -665,9 +886,11 @@ __device__ __forceinline__ void request_item(const KArgs& a, int w, int tid, Ite
         L.treg[i] = (idx < VT_NY * VT_NTOT) ? a.tabs[idx] : 0.0;
     }
     if (!kInline) {                                      // (one-launch variant: the workgroup sets the live point up itself)
-        L.hd = a.hdr[s];
-        const double* gr = a.recs + (size_t)s * recTotal;
-        const double* gt = a.taps + (a.taps_shared ? 0 : (size_t)s * tapTotal);
+        // (plain, cached loads in both cases.  Streaming launch: the row was set up by a wave of THIS XCD -- its L2 holds
+        // what was written -- and owns its 128-byte lines, so this CU's L1 has not seen them before)
+        const double* gr = a.recs + (size_t)s * (kCoh ? a.rec_stride : recTotal);
+        const double* gt = a.taps + (kCoh ? (size_t)s * a.tap_stride : (a.taps_shared ? 0 : (size_t)s * tapTotal));
+        L.hd = kCoh ? *reinterpret_cast<const SampleHdr*>(reinterpret_cast<const double*>(a.hdr) + (size_t)s * a.hdr_stride) : a.hdr[s];
 #pragma unroll
         for (int i = 0; i < kRecRegs; ++i) L.rreg[i] = (tid + i * kBlock < recTotal) ? gr[tid + i * kBlock] : 0.0;
         L.tapreg = (tid < tapTotal) ? gt[tid] : 0.0;
@@ -709,9 +932,11 @@ __device__ __forceinline__ void request_item(const KArgs& a, int w, int tid, Ite
 // kInline (small calls -- the one-theta-at-a-time solvers): there is no set-up kernel; wave 0 of the workgroup runs
 // setup_sample() for its live point straight into LDS (one launch instead of two on a latency-bound path; every tile of
 // a tiled spectrum repeats the set-up, which costs nothing when the chip is empty).
-template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync, bool kInline>
-__global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {
-    extern __shared__ __align__(16) double smem[];
+// kStream (the host-pointer entries' large batches): ONE launch for the whole call, no set-up kernel, no copy command.
+// The grid sets the live points up itself (stream_setup_phase) while the parameter rows are still arriving in the
+// page-locked block the kernel reads them from, and an item goes to the component loop once its row's stamp is there.
+template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync, bool kInline, bool kStream>
+__device__ __forceinline__ void fused_items(const KArgs& a, double* smem) {
     double* sTab = smem;                                   // 2 x kLinesPerSync folded tables
     double* sRec = sTab + 2 * kLinesPerSync * kTabPad;                     // ncl_cap * 8
     double* sW = sRec + a.ncl_cap * kRecStride;            // taps, zero-padded to a multiple of 8
@@ -729,14 +954,42 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
     constexpr bool selfHalo = kSelfHalo;               // (a.selfhalo chooses the instantiation on the host)
     if (kFarInterp) sWt[(tid0 & 7) * 64 + (tid0 >> 3)] = a.wtab[tid0];      // kBlock == 64 * VT_INODES
     const int recTotal = a.ncl_cap * kRecStride, tapTotal = 2 * a.n_cap + 8;
-    const int nItems = a.nitems;
+    // streaming launch: this workgroup's XCD, whose queue hands out LOCAL tickets over the XCD's own live points
+    const int xcd = kStream ? xcd_id() : 0;
+    const int nItems = kStream ? stream_rows_of(a.nrows, xcd) * a.ntiles : a.nitems;
 
     // ticket -> work item: with an ordered hand-out, ticket t is tile (t % ntiles) of live point order[t / ntiles]
-    constexpr bool kOrdered = kSelfHalo && !kInline;   // (the host passes a.order only to these instantiations)
-    auto item_of = [&](int t) -> int { return (kOrdered && a.order) ? a.order[t] : t; };
-    int w = item_of(blockIdx.x);                       // grid <= nItems
+    constexpr bool kOrdered = kSelfHalo && !kInline && !kStream;   // (the host passes a.order only to these instantiations)
+    // ticket -> work item.  Streaming launch: local ticket t of the XCD = tile (t % ntiles) of its local live point t / ntiles
+    auto item_of = [&](int t) -> int {
+        if (kStream) { const int j = t / a.ntiles; return stream_row(xcd, j) * a.ntiles + (t - j * a.ntiles); }
+        return (kOrdered && a.order) ? a.order[t] : t;
+    };
+    // The next ticket is published to the workgroup behind the component loop -- where the queue's answer (and the
+    // order look-up) has long arrived -- rather than before the item's first barrier.  (A streaming launch's queue
+    // is shared by all XCDs: published at once, its atomic's round trip to memory sat on every item's path, +7 %.)
+    constexpr bool kDeferTicket = kOrdered || kStream;
+    int w;
+    unsigned int* const queue = kStream ? &a.sctl->queue[xcd] : a.queue;
+    // tickets the grid's workgroups start with (the queue continues behind them); the workgroups of a streaming launch
+    // -- whose set-up phase is over: see the kernel -- all start from their XCD's queue
+    const int firstTickets = kStream ? 0 : (int)gridDim.x;
+    if (kStream) {
+        if (tid0 == 0) sNext[0] = (int)atomicAdd(queue, 1u);
+        __syncthreads();
+        const int t = sNext[0];
+        __syncthreads();
+        if (t >= nItems) {                             // (workgroup-uniform) nothing left for a late-comer
+            stream_exit(a, tid0);
+            return;
+        }
+        w = item_of(t);
+        stream_wait_ready(a, w / a.ntiles, 0u);
+    } else {
+        w = item_of(blockIdx.x);                       // grid <= nItems
+    }
     ItemLoads L;
-    request_item<kZeroPad, kSelfHalo, kInline>(a, w, tid0, L);
+    request_item<kZeroPad, kSelfHalo, kInline, kStream>(a, w, tid0, L);
 
     while (true) {
         MCALF_STAMP(0);
@@ -795,12 +1048,12 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             for (int i = 0; i < kRecRegs; ++i)
                 if (tid + i * kBlock < recTotal) sRec[tid + i * kBlock] = L.rreg[i];
             if (recTotal > kRecRegs * kBlock) {
-                const double* gr = a.recs + (size_t)s * recTotal;
+                const double* gr = a.recs + (size_t)s * (kStream ? a.rec_stride : recTotal);
                 for (int i = tid + kRecRegs * kBlock; i < recTotal; i += kBlock) sRec[i] = gr[i];
             }
             if (tid < tapTotal) sW[tid] = L.tapreg;
             if (tapTotal > kBlock) {
-                const double* gt = a.taps + (a.taps_shared ? 0 : (size_t)s * tapTotal);
+                const double* gt = a.taps + (kStream ? (size_t)s * a.tap_stride : (a.taps_shared ? 0 : (size_t)s * tapTotal));
                 for (int i = tid + kBlock; i < tapTotal; i += kBlock) sW[i] = gt[i];
             }
         }
@@ -815,10 +1068,16 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         // dependent memory round trip -- so thread 0 keeps both in registers and publishes them behind the
         // component loop, where they have long arrived; otherwise the ticket is published at once.
         int tHeld = nItems, wHeld = 0;
+        unsigned stHeld = 0u;
         if (tid == 0) {
-            tHeld = a.persist ? (int)gridDim.x + (int)atomicAdd(a.queue, 1u) : nItems;
+            tHeld = a.persist ? firstTickets + (int)atomicAdd(queue, 1u) : nItems;
             if (kOrdered) wHeld = (tHeld < nItems) ? item_of(tHeld) : 0;
-            else { sNext[0] = tHeld; sNext[1] = tHeld; }
+            else if (kStream) {
+                // (streaming launch: thread 0 also takes a first look at the next row's stamp -- the answer lands while
+                // the component loop runs and travels to the workgroup with the ticket)
+                wHeld = (tHeld < nItems) ? item_of(tHeld) : 0;
+                if (tHeld < nItems) stHeld = __hip_atomic_load(a.ready + wHeld / a.ntiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else { sNext[0] = tHeld; sNext[1] = tHeld; }
         }
 
         MCALF_STAMP(1);
@@ -826,11 +1085,12 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         __syncthreads();                                   // publishes sRec, sW, sT, sNext (and the header of the one-launch variant)
         if (kInline) hd = *sHdr;
         const double cont = hd.cont, bot = hd.bot;
-        const int ncl = hd.ncl, n = hd.n;
+        // (streaming launch: a wait that ran out may leave a header nobody wrote -- keep its counts inside the buffers)
+        const int ncl = kStream ? min(max(hd.ncl, 0), a.ncl_cap) : hd.ncl, n = kStream ? min(max(hd.n, 0), a.n_cap) : hd.n;
         const bool bad = hd.bad != 0;
         const int shift = a.n_cap - n;
         int tNext = 0, wNext = 0;
-        if (!kOrdered) {
+        if (!kDeferTicket) {
             tNext = __builtin_amdgcn_readfirstlane(sNext[0]);            // the next ticket ...
             wNext = __builtin_amdgcn_readfirstlane(sNext[1]);            // ... and the work item it stands for
         }
@@ -960,12 +1220,16 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             asm volatile("" : "+v"(zero));                 // formed here: hoisted out of the item loop it was spilled
             sF[tile_pos(extTight + tid)] = zero;
         }
-        if (kOrdered && tid == 0) { sNext[0] = tHeld; sNext[1] = wHeld; }
+        if (kDeferTicket && tid == 0) { sNext[0] = tHeld; sNext[1] = wHeld; if (kStream) sNext[2] = (int)stHeld; }
         __syncthreads();
-        if (kOrdered) {
+        if (kDeferTicket) {
             tNext = __builtin_amdgcn_readfirstlane(sNext[0]);
             wNext = __builtin_amdgcn_readfirstlane(sNext[1]);
         }
+        // Streaming launch: thread 0's look at the next row's stamp (taken while the component loop ran; the set-up runs
+        // far ahead of the queue, so it normally says "set up" and nobody has to ask memory again)
+        unsigned stampNext = 0u;
+        if (kStream) stampNext = (unsigned)__builtin_amdgcn_readfirstlane(sNext[2]);
 
         MCALF_STAMP(4);
         // ---- 3+4. convolution, continuum, likelihood terms -------------------------------------
@@ -1076,7 +1340,8 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         // (unconditional -- the last item of a workgroup re-requests a valid item it never uses -- so that the
         // loads REDEFINE every register of L: behind a condition the old values would have to stay alive through
         // the whole item for the merge)
-        if (!kInline) request_item<kZeroPad, kSelfHalo, kInline>(a, more ? wNext : w, tid, L);   // (one-launch variant: one item per workgroup)
+        if (kStream && more) stream_wait_ready(a, wNext / a.ntiles, stampNext);
+        if (!kInline) request_item<kZeroPad, kSelfHalo, kInline, kStream>(a, more ? wNext : w, tid, L);   // (one-launch variant: one item per workgroup)
         __builtin_amdgcn_sched_barrier(0);
         if (reduces) {
             acc = wave_sum_to_last(acc);
@@ -1101,7 +1366,12 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
             MCALF_STAMP_SLOT(6);                         // (diagnostic builds: which workgroup slot ran the item)
             MCALF_STAMP(7);
             if (a.ntiles == 1) {
-                a.out[s] = finalize_value(a.mode, ssum, scnt, a.asymm != 0, t4, t5, a.veto4, a.veto5);
+                const double val = finalize_value(a.mode, ssum, scnt, a.asymm != 0, t4, t5, a.veto4, a.veto5);
+                // (streaming launch: the result goes to page-locked host memory and the host reads it as soon as the
+                // launch's completion word says so, ahead of the end-of-kernel cache write-back: a system-scope store,
+                // written through -- plain stores were seen to linger in one XCD's L2 past the completion word)
+                if (kStream) __hip_atomic_store(a.out + s, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else a.out[s] = val;
             } else {
                 double* pr = a.partial + ((size_t)s * a.ntiles + tileIdx) * 4;
                 pr[0] = ssum; pr[1] = scnt; pr[2] = t4; pr[3] = t5;
@@ -1109,6 +1379,31 @@ __global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(co
         }
         if (kInline || !more) break;                     // wave-uniform: every wave of the workgroup leaves here
         w = wNext;
+    }
+    if (kStream) stream_exit(a, tid0);
+}
+
+template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync, bool kInline, bool kStream>
+__global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {
+    static_assert(!(kInline && kStream), "the one-launch variant of small calls has no queue to stream through");
+    extern __shared__ __align__(16) double smem[];
+    if constexpr (kStream) {
+        stream_setup_phase<kZeroPad>(a, threadIdx.x, xcd_id(), reinterpret_cast<int*>(smem));
+
+        // The item loop reads its arguments afresh from the kernel-argument segment (through a pointer the compiler
+        // cannot see through): their live ranges then start HERE, as in the two-kernel variant.  With one set of
+        // values alive across both phases the set-up's scalar-register pressure spilled the loop's arguments for
+        // their whole life (183 scalar spills, ~500 more v_readlane reloads on every item's path).
+        // (a typed copy out of the constant address space: pointers loaded from there are known to be global, so the loop
+        // keeps its global_load / global_atomic instructions -- copied word by word they became generic pointers, and a
+        // FLAT load also counts as an LDS operation: every LDS wait of the loop then waited for HBM)
+        typedef __attribute__((address_space(4))) const KArgs ArgSeg;
+        ArgSeg* kp = (ArgSeg*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        KArgs fresh = *(const KArgs*)kp;                  // (an aggregate copy: the compiler splits it into scalar loads of typed fields)
+        fused_items<kZeroPad, kSelfHalo, kLinesPerSync, kInline, kStream>(fresh, smem);
+    } else {
+        fused_items<kZeroPad, kSelfHalo, kLinesPerSync, kInline, kStream>(a, smem);
     }
 }
 
@@ -1226,8 +1521,30 @@ struct mcalf_ctx {
     // page-locked staging of the host-pointer entries: parameter rows in, scalars out
     double* h_stage = nullptr;
     size_t cap_stage = 0;
+    // Streaming single launch of the host-pointer entries (run_host_stream): queues / stamps in HBM, the words the host
+    // and the kernel exchange in a page-locked, device-mapped block (h_ctl: [0] status, [1] generation of the last
+    // launch that has drained, [16] rows staged so far -- a cache line of its own)
+    // (ONE allocation: records, taps, parameter rows, headers, stamps of `cap_sws` live points, then the queues)
+    void* d_sws = nullptr;
+    size_t cap_sws = 0;
+    double *s_recs = nullptr, *s_taps = nullptr, *s_P = nullptr;
+    size_t s_rec_stride = 0, s_tap_stride = 0, s_hdr_stride = 0;
+    SampleHdr* s_hdr = nullptr;
+    StreamCtl* d_sctl = nullptr;
+    unsigned int* d_ready = nullptr;
+    volatile unsigned int* h_ctl = nullptr;
+    unsigned int* d_ctl = nullptr;          // the same words as the device sees them
+    unsigned int stream_gen = 0;
+    int stream_on = 1;                      // MCALF_STREAM=0: the row-block pipeline of round 2 instead
+    int stream_wgs = 16;                    // MCALF_STREAM_WGS: workgroups dedicated to the set-up while rows are outstanding
+    int stream_chunk = 32;                  // MCALF_STREAM_CHUNK: rows such a workgroup claims (and copies to HBM) at a time
+    int stream_trace = 0;                   // MCALF_STREAM_TRACE=1 (diagnostic): host-side time per phase of the streaming entry
+    int stream_device = 0;                  // MCALF_STREAM_DEVICE=1 (diagnostic): the *_device scalar entries take the streaming launch too
+    int stream_poll = 1;                    // MCALF_STREAM_POLL=0: wait for the stream's signal instead of polling h_ctl[1]
+    double stream_timeout_s = 0.5;          // MCALF_STREAM_TIMEOUT: longest wait of a wave inside the kernel
     mcalf_launch_info_t last = {};      // what the last call did (mcalf_last_launch)
 };
+constexpr int kCtlWords = 64, kCtlArrived = 16;
 
 static int set_err(mcalf_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
@@ -1296,15 +1613,29 @@ extern "C" const char* mcalf_last_error(const mcalf_ctx* ctx) {
 
 static void comm_release(mcalf_ctx* ctx);
 
+// MCALF_STREAM_TRACE=1 (diagnostic): mean host-side microseconds per phase of the streaming entry, printed when the
+// context is destroyed
+struct StreamTrace { double t[6] = {}; long n = 0; };
+static StreamTrace g_stream_trace;
+static inline double now_us() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
+static void stream_trace_report(const mcalf_ctx* ctx);
+
 extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     if (!ctx) return;
+    stream_trace_report(ctx);
     (void)hipSetDevice(ctx->device);
     comm_release(ctx);
     void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_err, ctx->d_tabs, ctx->d_lines, ctx->d_wtab, ctx->d_segok,
                     ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds, ctx->d_prior, ctx->d_recs, ctx->d_taps, ctx->d_hdr,
-                    ctx->d_queue, ctx->d_order};
+                    ctx->d_queue, ctx->d_order, ctx->d_sws};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (ctx->h_ctl) (void)hipHostFree((void*)ctx->h_ctl);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
@@ -1323,8 +1654,18 @@ extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
 
 // The instantiations of the fused kernel: (JAX semantics, self-halo tile, lines per barrier) for batches, and the
 // one-launch variant (set-up inside the kernel, always 4 lines per barrier) for small calls.
-static const void* fused_kernel_ptr(bool jax, bool selfhalo, int lps, bool inl = false) {
-#define MCALF_K(J, S, L, I) reinterpret_cast<const void*>(&mcalf_fused_kernel<J, S, L, I>)
+static const void* fused_kernel_ptr(bool jax, bool selfhalo, int lps, bool inl = false, bool stream = false) {
+#define MCALF_K(J, S, L, I) reinterpret_cast<const void*>(&mcalf_fused_kernel<J, S, L, I, false>)
+#define MCALF_KS(J, S, L) reinterpret_cast<const void*>(&mcalf_fused_kernel<J, S, L, false, true>)
+    if (stream) {
+        if (lps == 5) {
+            if (jax) return selfhalo ? MCALF_KS(true, true, 5) : MCALF_KS(true, false, 5);
+            return selfhalo ? MCALF_KS(false, true, 5) : MCALF_KS(false, false, 5);
+        }
+        if (jax) return selfhalo ? MCALF_KS(true, true, 4) : MCALF_KS(true, false, 4);
+        return selfhalo ? MCALF_KS(false, true, 4) : MCALF_KS(false, false, 4);
+    }
+#undef MCALF_KS
     if (inl) {
         if (jax) return selfhalo ? MCALF_K(true, true, 4, true) : MCALF_K(true, false, 4, true);
         return selfhalo ? MCALF_K(false, true, 4, true) : MCALF_K(false, false, 4, true);
@@ -1542,7 +1883,11 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
                              fused_kernel_ptr(false, false, 5), fused_kernel_ptr(false, true, 5),
                              fused_kernel_ptr(true, false, 5),  fused_kernel_ptr(true, true, 5),
                              fused_kernel_ptr(false, false, 4, true), fused_kernel_ptr(false, true, 4, true),
-                             fused_kernel_ptr(true, false, 4, true),  fused_kernel_ptr(true, true, 4, true)};
+                             fused_kernel_ptr(true, false, 4, true),  fused_kernel_ptr(true, true, 4, true),
+                             fused_kernel_ptr(false, false, 4, false, true), fused_kernel_ptr(false, true, 4, false, true),
+                             fused_kernel_ptr(true, false, 4, false, true),  fused_kernel_ptr(true, true, 4, false, true),
+                             fused_kernel_ptr(false, false, 5, false, true), fused_kernel_ptr(false, true, 5, false, true),
+                             fused_kernel_ptr(true, false, 5, false, true),  fused_kernel_ptr(true, true, 5, false, true)};
     for (const void* k : kernels)
         HIP_TRY(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -1572,6 +1917,14 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
             if (n > 0) ctx->host_plan_n = n;
         }
         if (const char* fp = std::getenv("MCALF_TEST_FAIL_PREFLIGHT")) ctx->fail_preflight = std::atoi(fp) != 0;
+        if (const char* e = std::getenv("MCALF_STREAM")) ctx->stream_on = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MCALF_STREAM_WGS")) ctx->stream_wgs = std::min(std::max(std::atoi(e), 1), ctx->num_cu);
+        if (const char* e = std::getenv("MCALF_STREAM_POLL")) ctx->stream_poll = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MCALF_STREAM_CHUNK")) ctx->stream_chunk = std::min(std::max(std::atoi(e) & ~7, 8), 512);
+        if (const char* e = std::getenv("MCALF_STREAM_DEVICE")) ctx->stream_device = std::atoi(e);
+        if (const char* e = std::getenv("MCALF_STREAM_TRACE")) ctx->stream_trace = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MCALF_STREAM_TIMEOUT")) { const double v = std::atof(e); if (v > 0.0 && v <= 60.0) ctx->stream_timeout_s = v; }
+
         const char* env = std::getenv("MCALF_CHUNKS");            // 0 / unset: automatic; n: exactly n row blocks
         if (env && *env) {
             const int v = std::atoi(env);
@@ -1642,13 +1995,12 @@ extern "C" int mcalf_reserve(mcalf_ctx* ctx, int64_t batch) {
 // `chunk` selects the row of the shared tap table this block writes and reads (fixed-resolution contexts).
 // `from_cube`: dP holds unit-cube rows, mapped through the prior box while decoding; d_theta (optional)
 // receives the transformed rows.
-static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0, int64_t nrows, int chunk,
-                        int targonly, int onecomp_fill, double* d_out, double* d_model, hipStream_t stream,
-                        bool from_cube, double* d_theta, bool timed_ok) {
-    const bool reduces = (mode == kModeLogL || mode == kModeChi2);
+// The kernel arguments of rows [row0, row0 + nrows) of a batch (everything but the launch geometry).
+static KArgs make_kargs(const mcalf_ctx* ctx, int mode, const double* dP, int64_t row0, int64_t nrows, int chunk,
+                        int targonly, int onecomp_fill, double* d_out, double* d_model, bool from_cube, double* d_theta) {
     const int rowlen = (mode == kModeOneComp) ? 5 : ctx->ndim;
     const size_t tapTotal = 2 * (size_t)ctx->n_cap + 8;
-    KArgs a;
+    KArgs a = {};
     a.taps_shared = (!ctx->freespecres && mode != kModeOneComp) ? 1 : 0;
     a.recs = ctx->d_recs + (size_t)row0 * ctx->ncl_cap * kRecStride;
     a.taps = ctx->d_taps + (a.taps_shared ? (size_t)chunk : (size_t)row0) * tapTotal;
@@ -1674,6 +2026,16 @@ static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0
     a.theta_out = (from_cube && d_theta) ? d_theta + (size_t)row0 * ctx->ndim : nullptr;
     a.prior_int = ctx->prior_int;
     a.nitems = (int)(nrows * ctx->ntiles);
+    a.nrows = (int)nrows;
+    a.queue = ctx->d_queue + chunk;
+    return a;
+}
+
+static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0, int64_t nrows, int chunk,
+                        int targonly, int onecomp_fill, double* d_out, double* d_model, hipStream_t stream,
+                        bool from_cube, double* d_theta, bool timed_ok) {
+    const bool reduces = (mode == kModeLogL || mode == kModeChi2);
+    KArgs a = make_kargs(ctx, mode, dP, row0, nrows, chunk, targonly, onecomp_fill, d_out, d_model, from_cube, d_theta);
     // Persistent grid = the workgroup slots of the chip (2 per CU: LDS and the 4 waves per SIMD the kernel's
     // registers allow); correctness does not depend on how many of them are resident at once.  Used once every
     // slot sees at least four items: measured on MI355X, 8 items per slot (config C) -3.5 % and 160 per slot
@@ -1681,7 +2043,6 @@ static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0
     // more than the two workgroup launches they replace, so small launches keep one workgroup per item.
     const int64_t slots = 2LL * ctx->num_cu;
     a.persist = (ctx->persist && a.nitems >= 4 * slots) ? 1 : 0;
-    a.queue = ctx->d_queue + chunk;
     // Ordered hand-out while a slot sees at most 16 items: measured on MI355X, config C's spectrum, -2.2 % kernel time
     // at 8 items per slot (4096 live points) and nothing at 64 (32768), where the ordering workgroup -- its keys no
     // longer fit its registers -- would lengthen the set-up kernel by 47 us instead.
@@ -1766,11 +2127,38 @@ static int launch_preflight(mcalf_ctx* ctx, int mode, int64_t batch) {
     return grow_sample_ws(ctx, batch);
 }
 
+static void stream_trace_report(const mcalf_ctx* ctx) {
+    if (!ctx->stream_trace || g_stream_trace.n == 0) return;
+    const double n = (double)g_stream_trace.n;
+    std::fprintf(stderr, "mcalf stream trace (%ld calls, us per call): pointer checks %.2f, prepare %.2f, launch %.2f, stage rows %.2f, "
+                 "wait %.2f, copy out %.2f\n", g_stream_trace.n, g_stream_trace.t[0] / n, g_stream_trace.t[1] / n, g_stream_trace.t[2] / n,
+                 g_stream_trace.t[3] / n, g_stream_trace.t[4] / n, g_stream_trace.t[5] / n);
+    g_stream_trace = StreamTrace();
+}
+
+static int stream_prepare(mcalf_ctx* ctx, int mode, int64_t batch);
+static int stream_launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, double* d_out, hipStream_t stream, int wgs,
+                         int64_t eager_rows, bool staged, bool host_rows);
+static bool stream_qualifies(const mcalf_ctx* ctx, int64_t batch);
+
 static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill,
                   double* d_out, double* d_model, hipStream_t stream, bool from_cube = false,
                   double* d_theta = nullptr) {
     if (batch == 0) return MCALF_OK;
     int rc;
+    // MCALF_STREAM_DEVICE=1 (diagnostic): device-pointer batches through the streaming single launch as well -- every
+    // row is there from the start, so the whole grid sets up eight live points per workgroup and goes on to the items
+    if (ctx->stream_device && (mode == kModeLogL || mode == kModeChi2) && !from_cube && !d_model && ctx->chunks_req <= 1 &&
+        stream_qualifies(ctx, batch)) {
+        if ((rc = stream_prepare(ctx, mode, batch))) return rc;
+        ctx->last.row_blocks = 1;
+        if (ctx->stream_device == 2) {                     // ... with the host entries' split: a few rows eagerly, the rest by dedicated workgroups
+            const int grid = 2 * ctx->num_cu, wgs = std::min((ctx->stream_wgs + kXcds - 1) / kXcds * kXcds, grid / 2 / kXcds * kXcds);
+            const int64_t first_rows = ((grid - wgs) / kXcds + ctx->ntiles - 1) / ctx->ntiles;
+            return stream_launch(ctx, mode, dP, batch, d_out, stream, wgs, (first_rows + 7) / 8, false, false);
+        }
+        return stream_launch(ctx, mode, dP, batch, d_out, stream, 0, batch, false, false);
+    }
     if ((rc = launch_preflight(ctx, mode, batch))) return rc;
     const int nchunks = ctx->profiling ? 1 : pick_chunks(ctx, batch);
     ctx->last.row_blocks = nchunks;
@@ -1907,7 +2295,7 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
     if (need > ctx->cap_stage) {
         if (ctx->h_stage) HIP_TRY(ctx, hipHostFree(ctx->h_stage));
         ctx->h_stage = nullptr; ctx->cap_stage = 0;
-        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_stage, need * sizeof(double), hipHostMallocMapped));
+        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_stage, need * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
         ctx->cap_stage = need;
     }
     double* stage_in = pin_in ? nullptr : ctx->h_stage;
@@ -1957,6 +2345,212 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
     return MCALF_OK;
 }
 
+// Large scalar-output batches through host pointers, the default plan: ONE streaming launch, no copy commands.
+//
+//   host                                         device (mcalf_fused_kernel<..., kStream = true>, the persistent grid)
+//   launch the kernel                            every workgroup: set up eight of the first `eager_rows` live points
+//   pageable P: copy the rows into the           (the rows the grid's first items need), reading the parameter rows
+//     page-locked block, 128 at a time,          over PCIe from the page-locked block; then walk over work items.  The first
+//     publishing the count after each            `stream_wgs` workgroups go on setting up the remaining rows, in ticket order,
+//   (page-locked P: nothing to do)               as the host's count allows, and join the others at the item queue afterwards.
+//   poll the word the last workgroup out         An item enters the component loop once its row's stamp is there; logL goes
+//     writes; copy logL out if pageable          straight into page-locked memory; the last workgroup out re-arms the queues.
+//
+// Against the row-block pipeline (run_host_pipelined) this removes the copy commands, three of four set-up launches and
+// the tails of the sub-threshold launches, and the GPU starts before a single row has been staged.  `*taken` = false when
+// the call does not qualify (the caller then runs the pipeline); a wait that runs out inside the kernel (host thread
+// stalled for longer than MCALF_STREAM_TIMEOUT) fails over to the pipeline too, after the grid has drained.
+// Workspaces of the streaming launch for `batch` live points, and the words it shares with the host.
+static int stream_prepare(mcalf_ctx* ctx, int mode, int64_t batch) {
+    int rc;
+    const bool reduces = (mode == kModeLogL || mode == kModeChi2);
+    if (reduces && ctx->ntiles > 1 && (rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4)))
+        return rc;
+    if ((size_t)batch > ctx->cap_sws) {
+        // the launch's waves hand these to each other while it runs, through system-scope accesses (see the streaming
+        // helpers); ordinary device memory
+        // (every live point's records, taps and header start on a 128-byte line of their own)
+        ctx->s_rec_stride = ((size_t)ctx->ncl_cap * kRecStride + 15) & ~(size_t)15;
+        ctx->s_tap_stride = (2 * (size_t)ctx->n_cap + 8 + 15) & ~(size_t)15;
+        ctx->s_hdr_stride = 16;
+        const size_t nrec = (size_t)batch * ctx->s_rec_stride, ntap = (size_t)batch * ctx->s_tap_stride, nhdr = (size_t)batch * ctx->s_hdr_stride;
+        const size_t npar = ((size_t)batch * ctx->ndim + 15) & ~(size_t)15;
+        const size_t bytes = (nrec + ntap + nhdr + npar) * sizeof(double) + (size_t)batch * sizeof(unsigned int) + 256;
+        if (ctx->d_sws) HIP_TRY(ctx, hipFree(ctx->d_sws));
+        ctx->d_sws = nullptr; ctx->cap_sws = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_sws, bytes));
+        HIP_TRY(ctx, hipMemset(ctx->d_sws, 0, bytes));                                      // (stamps start at 1, queues at 0)
+        HIP_TRY(ctx, hipDeviceSynchronize());            // (the fill may still be running, and the launch streams do not wait for the null stream)
+        ctx->s_recs = static_cast<double*>(ctx->d_sws);
+        ctx->s_taps = ctx->s_recs + nrec;
+        ctx->s_hdr = reinterpret_cast<SampleHdr*>(ctx->s_taps + ntap);
+        ctx->s_P = ctx->s_taps + ntap + nhdr;
+        ctx->d_ready = reinterpret_cast<unsigned int*>(ctx->s_P + npar);
+        ctx->d_sctl = reinterpret_cast<StreamCtl*>((reinterpret_cast<uintptr_t>(ctx->d_ready + batch) + 63) & ~(uintptr_t)63);
+        ctx->cap_sws = (size_t)batch;
+        ctx->stream_gen = 0;
+    }
+    if (!ctx->h_ctl) {
+        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_ctl, kCtlWords * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset((void*)ctx->h_ctl, 0, kCtlWords * sizeof(unsigned int));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->d_ctl, (void*)ctx->h_ctl, 0));
+    }
+    return MCALF_OK;
+}
+
+// Enqueue ONE streaming launch over `batch` live points (and the finalize kernel of a tiled spectrum) on `stream`.
+// dP: the parameter rows as the DEVICE addresses them (HBM, or page-locked host memory); wgs: workgroups dedicated to
+// the set-up while rows are outstanding (a multiple of the XCD count: so many per XCD); eager_rows: blocks of eight
+// rows PER XCD that any of its workgroups may set up; staged: the kernel waits for the host's row count
+// (ctx->h_ctl[kCtlArrived]).
+static int stream_launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, double* d_out, hipStream_t stream, int wgs,
+                         int64_t eager_rows, bool staged, bool host_rows) {
+    KArgs a = make_kargs(ctx, mode, dP, 0, batch, 0, 0, 0, d_out, nullptr, false, nullptr);
+    a.taps_shared = 0;                                    // (a row's stamp covers its own taps only)
+    a.recs = ctx->s_recs; a.taps = ctx->s_taps; a.hdr = ctx->s_hdr;
+    a.persist = 1;
+    a.order = nullptr;
+    const int grid = 2 * ctx->num_cu;
+    if (++ctx->stream_gen == 0u) {                        // stamps wrapped: none of the old ones may match again
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        HIP_TRY(ctx, hipMemset(ctx->d_ready, 0, ctx->cap_sws * sizeof(unsigned int)));
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        ctx->stream_gen = 1u;
+    }
+    a.sctl = ctx->d_sctl;
+    a.ready = ctx->d_ready;
+    a.status = ctx->d_ctl;
+    a.arrived = staged ? ctx->d_ctl + kCtlArrived : nullptr;
+    a.gen = ctx->stream_gen;
+    a.stream_wgs = wgs / kXcds;                           // (per XCD)
+    a.eager_rows = (int)std::min<int64_t>((batch + 7) / 8, eager_rows);      // (local blocks of eight rows per XCD)
+    a.spin_ticks = (long long)(ctx->stream_timeout_s * 1e8);
+    a.rec_stride = (int)ctx->s_rec_stride; a.tap_stride = (int)ctx->s_tap_stride; a.hdr_stride = (int)ctx->s_hdr_stride;
+    a.Pdev = host_rows ? ctx->s_P : nullptr;
+    a.rest_chunk = ctx->stream_chunk;
+    ctx->last.persistent = 1; ctx->last.grid = grid; ctx->last.items = a.nitems; ctx->last.lines_per_sync = ctx->lps;
+    ctx->last.selfhalo = ctx->selfhalo; ctx->last.ordered = 0; ctx->last.inline_setup = 0;
+    ctx->last.stream_setup_wgs = wgs;
+    const bool timed = ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used], stream));
+    {
+        void* kargs[] = {(void*)&a};
+        HIP_TRY(ctx, hipLaunchKernel(fused_kernel_ptr(ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX, ctx->selfhalo != 0, ctx->lps, false, true),
+                                     dim3((unsigned)grid), dim3(kBlock), kargs, ctx->lds_bytes, stream));
+    }
+    if (timed) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], stream));
+        ctx->ev_used += 2;
+    }
+    if ((mode == kModeLogL || mode == kModeChi2) && ctx->ntiles > 1) {
+        const int fb = 256;
+        hipLaunchKernelGGL(mcalf_finalize_kernel, dim3((unsigned)((batch + fb - 1) / fb)), dim3(fb), 0, stream,
+                           a.partial, a.out, (long)batch, ctx->ntiles, mode, a.asymm, a.veto4, a.veto5);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return MCALF_OK;
+}
+
+static bool stream_qualifies(const mcalf_ctx* ctx, int64_t batch) {
+    const int64_t slots = 2LL * ctx->num_cu, nitems = batch * ctx->ntiles;
+    return ctx->persist && nitems >= 4 * slots && nitems <= 0x7fff0000LL && batch <= 0x7fff0000LL;
+}
+
+static int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, double* out_scalar, bool* taken) {
+    *taken = false;
+    const bool trace = ctx->stream_trace;
+    double tm[7] = {};
+    if (trace) tm[0] = now_us();
+    if (!ctx->stream_on || ctx->chunks_req > 0 || ctx->host_plan_n > 0 || ctx->profiling || !stream_qualifies(ctx, batch)) return MCALF_OK;
+    const bool pin_in = is_pinned_host(P), pin_out = is_pinned_host(out_scalar);
+    const double* dP_view = nullptr;
+    if (pin_in && hipHostGetDevicePointer((void**)&dP_view, const_cast<double*>(P), 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return MCALF_OK;                                  // page-locked but not device-mapped: the copy engines' job
+    }
+    double* d_out_view = nullptr;
+    if (pin_out && hipHostGetDevicePointer((void**)&d_out_view, out_scalar, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return MCALF_OK;
+    }
+    int rc;
+    if (trace) tm[1] = now_us();
+    if ((rc = stream_prepare(ctx, mode, batch))) return rc;
+    const size_t need = (pin_in ? 0 : (size_t)batch * rowlen) + (pin_out ? 0 : (size_t)batch);
+    if (need > ctx->cap_stage) {
+        if (ctx->h_stage) HIP_TRY(ctx, hipHostFree(ctx->h_stage));
+        ctx->h_stage = nullptr; ctx->cap_stage = 0;
+        // coherent: the kernel reads rows of this block while the host is still writing later ones
+        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_stage, need * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        ctx->cap_stage = need;
+    }
+    double* stage_in = pin_in ? nullptr : ctx->h_stage;
+    double* stage_out = pin_out ? out_scalar : ctx->h_stage + (pin_in ? 0 : (size_t)batch * rowlen);
+    if (!pin_in) HIP_TRY(ctx, hipHostGetDevicePointer((void**)&dP_view, stage_in, 0));
+    if (!pin_out) HIP_TRY(ctx, hipHostGetDevicePointer((void**)&d_out_view, stage_out, 0));
+    const int grid = 2 * ctx->num_cu;
+    const int wgs = std::min((ctx->stream_wgs + kXcds - 1) / kXcds * kXcds, grid / 2 / kXcds * kXcds);
+    // the rows the first items of an XCD's workgroups need: (workgroups per XCD - dedicated ones) tickets of its queue
+    const int64_t first_rows = ((grid - wgs) / kXcds + ctx->ntiles - 1) / ctx->ntiles;
+    ctx->h_ctl[0] = 0u;
+    ctx->h_ctl[kCtlArrived] = 0u;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    ctx->last.path = MCALF_PATH_HOST_STREAM; ctx->last.row_blocks = 1;
+    ctx->last.pinned_in = pin_in ? 1 : 0; ctx->last.pinned_out = pin_out ? 1 : 0;
+    if (trace) tm[2] = now_us();
+    // the rows an XCD's first items need are set up by whichever of its workgroups gets there first, the rest by its
+    // dedicated workgroups
+    if ((rc = stream_launch(ctx, mode, dP_view, batch, d_out_view, ctx->stream, wgs, (first_rows + 7) / 8, !pin_in, true)))
+        return rc;
+    const bool tiled = (mode == kModeLogL || mode == kModeChi2) && ctx->ntiles > 1;
+    if (trace) tm[3] = now_us();
+    // The kernel is in flight (or about to be): stage the rows.  Nothing below can fail before every row has been
+    // published, so the grid never waits for a row that is not coming.
+    if (!pin_in) {
+        constexpr int64_t kRowsPerStep = 128;
+        for (int64_t r0 = 0; r0 < batch; r0 += kRowsPerStep) {
+            const int64_t n = std::min(kRowsPerStep, batch - r0);
+            std::memcpy(stage_in + (size_t)r0 * rowlen, P + (size_t)r0 * rowlen, (size_t)n * rowlen * sizeof(double));
+            __atomic_store_n(const_cast<unsigned int*>(ctx->h_ctl + kCtlArrived), (unsigned int)(r0 + n), __ATOMIC_RELEASE);
+        }
+    }
+    hipError_t he = hipGetLastError();
+    if (trace) tm[4] = now_us();
+    // Completion: the word the last workgroup writes once every result has been acknowledged (a stream wait costs an
+    // interrupt and a thread wake-up); the stream is asked now and then so that a faulted launch cannot keep us here.
+    bool polled = false;
+    if (he == hipSuccess && ctx->stream_poll && !tiled) {
+        const unsigned int want = ctx->stream_gen;
+        for (unsigned long spins = 0;; ++spins) {
+            if (__atomic_load_n(const_cast<unsigned int*>(ctx->h_ctl + 1), __ATOMIC_ACQUIRE) == want) { polled = true; break; }
+            if ((spins & 0xFFFFul) == 0xFFFFul && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;
+            __builtin_ia32_pause();
+        }
+    }
+    if (!polled) {
+        const hipError_t se = hipStreamSynchronize(ctx->stream);
+        if (he == hipSuccess) he = se;
+    }
+    ctx->last.stream_polled = polled ? 1 : 0;
+    if (he != hipSuccess) return set_err(ctx, MCALF_ERR_HIP, "streaming launch failed: %s", hipGetErrorString(he));
+    if (ctx->h_ctl[0] != 0u) {
+        // a wave ran out of patience (the grid has drained by now): not an answer -- the caller goes the pipelined way
+        (void)hipStreamSynchronize(ctx->stream);
+        HIP_TRY(ctx, hipMemset(ctx->d_sctl, 0, sizeof(StreamCtl)));
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        return MCALF_OK;
+    }
+    if (trace) tm[5] = now_us();
+    if (!pin_out) std::memcpy(out_scalar, stage_out, (size_t)batch * sizeof(double));
+    if (trace) {
+        tm[6] = now_us();
+        for (int k = 0; k < 6; ++k) g_stream_trace.t[k] += tm[k + 1] - tm[k];
+        g_stream_trace.n++;
+    }
+    *taken = true;
+    return MCALF_OK;
+}
+
 // Host-pointer entries: stage through the context's workspaces on its private stream.
 static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
                     double* out_scalar, double* out_model) {
@@ -1983,7 +2577,13 @@ static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
     if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, (size_t)batch * rowlen))) return rc;
     if (out_scalar && (rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
     if (out_model && (rc = grow(ctx, &ctx->d_model, &ctx->cap_model, (size_t)batch * ctx->npix))) return rc;
-    if (out_scalar && !out_model) return run_host_pipelined(ctx, mode, P, batch, rowlen, targonly, fill, out_scalar);
+    if (out_scalar && !out_model) {
+        if (mode == kModeLogL || mode == kModeChi2) {
+            bool taken = false;
+            if ((rc = run_host_stream(ctx, mode, P, batch, rowlen, out_scalar, &taken)) != MCALF_OK || taken) return rc;
+        }
+        return run_host_pipelined(ctx, mode, P, batch, rowlen, targonly, fill, out_scalar);
+    }
     ctx->last.path = MCALF_PATH_HOST_STAGED; ctx->last.pinned_in = ctx->last.pinned_out = 0;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_P, P, (size_t)batch * rowlen * sizeof(double), hipMemcpyHostToDevice,
                                 ctx->stream));
@@ -2042,7 +2642,12 @@ struct RcclApi {
 };
 RcclApi g_rccl;
 
+std::mutex g_rccl_mutex;
+
+// (serialised: contexts of several host threads may reach their first mcalf_comm_* call together; a failed load is
+// retried by the next call)
 int rccl_load(mcalf_ctx* ctx) {
+    std::lock_guard<std::mutex> guard(g_rccl_mutex);
     if (g_rccl.ok) return MCALF_OK;
     const char* names[] = {"librccl.so.1", "librccl.so"};
     void* h = nullptr;
@@ -2341,10 +2946,11 @@ static int hjerting_impl(const double* x, const double* y, int64_t n, double* ou
     HIP_TRY(nullptr, hipSetDevice(dev));
     double *dx = nullptr, *dy = nullptr, *dout = nullptr, *dtabs = nullptr;
     const size_t nb = (size_t)n * sizeof(double);
-    HIP_TRY(nullptr, hipMalloc((void**)&dx, nb));
-    HIP_TRY(nullptr, hipMalloc((void**)&dy, nb));
-    HIP_TRY(nullptr, hipMalloc((void**)&dout, nb));
-    rc = upload_tables(nullptr, &dtabs);
+    hipError_t em = hipMalloc((void**)&dx, nb);
+    if (em == hipSuccess) em = hipMalloc((void**)&dy, nb);
+    if (em == hipSuccess) em = hipMalloc((void**)&dout, nb);
+    if (em != hipSuccess) rc = set_err(nullptr, MCALF_ERR_HIP, "hjerting: hipMalloc failed: %s", hipGetErrorString(em));
+    else rc = upload_tables(nullptr, &dtabs);
     if (rc == MCALF_OK) {
         hipError_t e = hipMemcpy(dx, x, nb, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(dy, y, nb, hipMemcpyHostToDevice);
@@ -2356,8 +2962,8 @@ static int hjerting_impl(const double* x, const double* y, int64_t n, double* ou
         if (e == hipSuccess) e = hipMemcpy(out, dout, nb, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = set_err(nullptr, MCALF_ERR_HIP, "hjerting: %s", hipGetErrorString(e));
     }
-    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
-    if (dtabs) (void)hipFree(dtabs);
+    for (double* b : {dx, dy, dout, dtabs})
+        if (b) (void)hipFree(b);
     return rc;
 }
 

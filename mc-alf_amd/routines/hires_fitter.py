@@ -17,6 +17,7 @@ replaced by an explicit `linepars=` argument plus a tiny built-in table (`LINE_T
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import gc
 from typing import Optional, Sequence
 
@@ -229,6 +230,27 @@ class als_fitter:
         _lib.check(lib.mcalf_info(ctx, C.byref(info)), ctx)
         assert info.ndim == self.ndim and info.startind == self.startind and info.endind == self.endind
         self.info = info
+        # host-side call overhead matters for the one-theta-at-a-time solvers (a call is ~40 us on the GPU side):
+        # one persistent parameter row / result slot with their addresses taken once, and a small cache of the
+        # addresses of the caller's arrays (a sampler hands over the same buffers call after call)
+        self._p1 = np.empty((1, self.ndim))
+        self._o1 = np.empty(1)
+        self._p1_ptr, self._o1_ptr = self._p1.ctypes.data, self._o1.ctypes.data
+        self._ptrs = {}
+
+    def _ptr(self, arr):
+        """Address of a C-contiguous array's data (cached per array object: `ndarray.ctypes` costs a microsecond)."""
+        hit = self._ptrs.get(id(arr))
+        if hit is not None and hit[0]() is arr:
+            return hit[1]
+        ptr = arr.ctypes.data
+        if len(self._ptrs) >= 16:
+            self._ptrs.clear()
+        try:
+            self._ptrs[id(arr)] = (weakref.ref(arr), ptr)
+        except TypeError:                                   # (an array type that cannot be weakly referenced)
+            pass
+        return ptr
 
     def close(self):
         twin = getattr(self, "_twin", None)
@@ -332,9 +354,9 @@ class als_fitter:
             out = np.empty(P.shape[0])
         elif out.dtype != np.float64 or not out.flags.c_contiguous or out.size != P.shape[0]:
             raise ValueError("out must be a C-contiguous float64 array with one entry per row")
-        pd = C.POINTER(C.c_double)
-        _lib.check(self._lib.mcalf_loglike_batch(self._ctx, P.ctypes.data_as(pd), P.shape[0],
-                                                 out.ctypes.data_as(pd)), self._ctx)
+        rc = self._lib.mcalf_loglike_batch(self._ctx, self._ptr(P), P.shape[0], self._ptr(out))
+        if rc:
+            _lib.check(rc, self._ctx)
         return out
 
     def chi2_batch(self, P):
@@ -405,7 +427,14 @@ class als_fitter:
     def lnlhood_worker(self, p):
         """hires_fitter.py:287-328."""
         self._check_scalar(p)
-        return float(self.loglike_batch(p)[0])
+        p = np.asarray(p, dtype=float)
+        if p.shape != (self.ndim,):
+            return float(self.loglike_batch(p)[0])          # (raises for a wrong length, as the batched entry does)
+        self._p1[0, :] = p
+        rc = self._lib.mcalf_loglike_batch(self._ctx, self._p1_ptr, 1, self._o1_ptr)
+        if rc:
+            _lib.check(rc, self._ctx)
+        return float(self._o1[0])
 
     def reconstruct_spec(self, p, targonly=False):
         """hires_fitter.py:409-449."""

@@ -152,9 +152,9 @@ def test_edge_cases(cfgB):
         for v in (0.0, 0.9, -3.0):
             q[0] = v
             # no absorber: the model is the LSF applied to a constant, sum(w) / bot.  astropy forms both sums in
-            # one loop, so the reference gives exactly 1; here `bot` comes from the set-up kernel's wave reduction
-            # and the numerator from the tap-ordered FMA chain: equal to the last bit or one ulp apart
-            assert np.abs(fit.reconstruct_spec(q) - 1.0).max() <= 2.3e-16
+            # one loop, tap after tap, so the reference gives exactly 1 (hires_fitter.py:463-464); the set-up code
+            # adds the taps up in the order of the fused kernel's numerator chain for the same reason
+            assert np.all(fit.reconstruct_spec(q) == 1.0)
         q[0] = 3.7                      # int() -> 3
         assert np.abs(fit.reconstruct_spec(q) - o.reconstruct_spec(prob, q)).max() < 1e-11
         # (3) empty batch

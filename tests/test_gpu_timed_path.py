@@ -85,9 +85,11 @@ def test_persistent_switch_is_really_taken_and_changes_nothing(monkeypatch):
 
 
 def test_pipelined_host_entry_is_the_path_taken_and_is_bit_equal(monkeypatch):
-    """Large scalar-output calls through host pointers (batch * ndim > 65536 doubles) run `run_host_pipelined`:
+    """Large scalar-output calls through host pointers (batch * ndim > 65536 doubles).  Default plan: ONE streaming
+    launch (`run_host_stream`, MCALF_PATH_HOST_STREAM) once the launch reaches the persistent-grid threshold; an
+    explicit block count, MCALF_HOST_PLAN or MCALF_STREAM=0 select the row-block pipeline (`run_host_pipelined`):
     pageable arrays are staged, page-locked ones are used by the copy engines directly and the kernels write logL
-    into the caller's page-locked array.  Every block plan gives the device entry's bits."""
+    into the caller's page-locked array.  Every plan gives the device entry's bits."""
     kw, _, seed = workloads.config("C", oracle_synth)
     n = 2600
     P = workloads.draw_P(kw, n, np.random.default_rng(seed + 13))
@@ -97,16 +99,17 @@ def test_pipelined_host_entry_is_the_path_taken_and_is_bit_equal(monkeypatch):
     with mcalf_amd.als_fitter(None, **kw) as fit:
         whole = _device_logl(fit, dP, n)
         assert np.isfinite(whole).all()
-        for k, blocks_pageable, blocks_pinned in ((0, 4, 2), (1, 1, 1), (2, 2, 2), (5, 5, 5)):
+        for k, blocks_pageable, blocks_pinned in ((0, 1, 1), (1, 1, 1), (2, 2, 2), (5, 5, 5)):
             fit.set_chunks(k)
+            path = _lib.MCALF_PATH_HOST_STREAM if k == 0 else _lib.MCALF_PATH_HOST_PIPELINED
             got = fit.loglike_batch(P)
             ll = fit.last_launch()
-            assert (ll.path, ll.row_blocks, ll.pinned_in, ll.pinned_out) == (_lib.MCALF_PATH_HOST_PIPELINED, blocks_pageable, 0, 0)
+            assert (ll.path, ll.row_blocks, ll.pinned_in, ll.pinned_out) == (path, blocks_pageable, 0, 0)
             assert np.array_equal(got, whole), k
             opin = torch.full((n,), float("nan"), dtype=torch.float64).pin_memory().numpy()
             fit.loglike_batch(Ppin, out=opin)
             ll = fit.last_launch()
-            assert (ll.path, ll.row_blocks, ll.pinned_in, ll.pinned_out) == (_lib.MCALF_PATH_HOST_PIPELINED, blocks_pinned, 1, 1)
+            assert (ll.path, ll.row_blocks, ll.pinned_in, ll.pinned_out) == (path, blocks_pinned, 1, 1)
             assert np.array_equal(opin, whole), k
             # mixed: page-locked rows, pageable results
             mixed = np.full(n, np.nan)
@@ -118,6 +121,24 @@ def test_pipelined_host_entry_is_the_path_taken_and_is_bit_equal(monkeypatch):
         # small calls take the zero-copy block instead
         assert np.array_equal(fit.loglike_batch(P[:100]), whole[:100])
         assert fit.last_launch().path == _lib.MCALF_PATH_HOST_ZEROCOPY
+        # below the persistent-grid threshold (4 items per workgroup slot) a large call is pipelined in row blocks
+        nsmall = 1500
+        assert nsmall * P.shape[1] > 65536
+        assert np.array_equal(fit.loglike_batch(P[:nsmall]), whole[:nsmall])
+        ll = fit.last_launch()
+        assert (ll.path, ll.row_blocks) == (_lib.MCALF_PATH_HOST_PIPELINED, 4)
+    # the row-block pipeline as the default plan (MCALF_STREAM=0): 1 : 1 : 2 : 4 pageable, 1 : 7 page-locked
+    monkeypatch.setenv("MCALF_STREAM", "0")
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        assert np.array_equal(fit.loglike_batch(P), whole)
+        ll = fit.last_launch()
+        assert (ll.path, ll.row_blocks, ll.pinned_in) == (_lib.MCALF_PATH_HOST_PIPELINED, 4, 0)
+        opin = torch.full((n,), float("nan"), dtype=torch.float64).pin_memory().numpy()
+        fit.loglike_batch(Ppin, out=opin)
+        ll = fit.last_launch()
+        assert (ll.path, ll.row_blocks, ll.pinned_in, ll.pinned_out) == (_lib.MCALF_PATH_HOST_PIPELINED, 2, 1, 1)
+        assert np.array_equal(opin, whole)
+    monkeypatch.delenv("MCALF_STREAM")
     # explicit relative plans; 1 : 1 : 5000 of 2600 rows leaves block 0 EMPTY and one row in block 1
     for plan in ("1,3,4", "1,1,5000"):
         monkeypatch.setenv("MCALF_HOST_PLAN", plan)
@@ -132,6 +153,83 @@ def test_pipelined_host_entry_is_the_path_taken_and_is_bit_equal(monkeypatch):
         assert fit.last_launch().path == _lib.MCALF_PATH_HOST_PIPELINED
         fit.set_chunks(1)
         assert np.array_equal(fit.loglike_batch(PE), a)
+
+
+@pytest.mark.parametrize("cfg,conv,n", [("C", "numpy", 4096), ("C", "jax", 2300), ("E", "numpy", 1400), ("B", "numpy", 2700)])
+def test_streaming_host_entry_one_launch_no_copy_commands(cfg, conv, n, monkeypatch):
+    """`run_host_stream`: the whole call is ONE launch of `mcalf_fused_kernel<..., kStream = true>` -- the grid reads the
+    parameter rows from page-locked memory while the host is still staging them, sets the live points up itself (every
+    XCD its own rows: a few dedicated workgroups per XCD run ahead of the XCD's item queue) and writes logL into
+    page-locked memory.  Asserted to be the path
+    taken, for pageable / page-locked / mixed arrays, single- and multi-tile spectra, both boundary modes, logL and chi2;
+    bit-equal to the device entry (set-up kernel + fused kernel) and within tolerance of the C oracle on every row; the
+    set-up geometry (dedicated workgroups, rows per claim, completion by polling or by the stream) changes nothing; a
+    wait that runs out inside the kernel fails over to the row-block pipeline with the same bits."""
+    kw, _, seed = workloads.config(cfg, oracle_synth)
+    kw = dict(kw, conv_mode=conv)
+    P = workloads.draw_P(kw, n, np.random.default_rng(seed + 77), damped=2 if cfg == "E" else 0)
+    assert P.size > 65536
+    Ppin = torch.from_numpy(P).pin_memory().numpy()
+    dP = torch.from_numpy(P).cuda()
+    ref = {}
+    for env in ({}, {"MCALF_STREAM_WGS": "40", "MCALF_STREAM_CHUNK": "8"}, {"MCALF_STREAM_WGS": "5", "MCALF_STREAM_CHUNK": "104"},
+                {"MCALF_STREAM_POLL": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with mcalf_amd.als_fitter(None, **kw) as fit:
+            if not ref:
+                ref["logl"] = _device_logl(fit, dP, n)
+                assert fit.last_launch().path == _lib.MCALF_PATH_DEVICE
+                fit.set_chunks(1)
+                ref["chi2"] = fit.chi2_batch(P)                   # (an explicit block count: the pipeline, one block)
+                assert fit.last_launch().path == _lib.MCALF_PATH_HOST_PIPELINED
+                fit.set_chunks(0)
+            for rep in range(3):
+                if rep == 1:
+                    # a DIFFERENT matrix in between (the rows in reverse order): the workspaces the waves of a launch
+                    # hand each other are reused by every call, and a stale read of the previous call's records must
+                    # not hide behind identical values
+                    assert np.array_equal(fit.loglike_batch(P[::-1].copy()), ref["logl"][::-1]), (env, "reversed")
+                    assert fit.last_launch().path == _lib.MCALF_PATH_HOST_STREAM
+                    continue
+                got = fit.loglike_batch(P)
+                ll = fit.last_launch()
+                assert (ll.path, ll.row_blocks, ll.persistent, ll.ordered, ll.pinned_in, ll.pinned_out) == \
+                    (_lib.MCALF_PATH_HOST_STREAM, 1, 1, 0, 0, 0)
+                assert ll.grid == 2 * torch.cuda.get_device_properties(0).multi_processor_count
+                assert ll.items == n * fit.info.ntiles
+                assert ll.stream_setup_wgs == -(-int(env.get("MCALF_STREAM_WGS", 16)) // 8) * 8    # (so many per XCD)
+                assert ll.stream_polled == (0 if (env.get("MCALF_STREAM_POLL") == "0" or fit.info.ntiles > 1) else 1)
+                assert np.array_equal(got, ref["logl"]), (env, rep)
+            opin = torch.full((n,), float("nan"), dtype=torch.float64).pin_memory().numpy()
+            fit.loglike_batch(Ppin, out=opin)
+            ll = fit.last_launch()
+            assert (ll.path, ll.pinned_in, ll.pinned_out) == (_lib.MCALF_PATH_HOST_STREAM, 1, 1)
+            assert np.array_equal(opin, ref["logl"]), env
+            mixed = np.full(n, np.nan)
+            fit.loglike_batch(Ppin, out=mixed)
+            assert (fit.last_launch().pinned_in, fit.last_launch().pinned_out) == (1, 0)
+            assert np.array_equal(mixed, ref["logl"])
+            assert np.array_equal(fit.chi2_batch(P), ref["chi2"], equal_nan=True)
+            assert fit.last_launch().path == _lib.MCALF_PATH_HOST_STREAM
+        for k in env:
+            monkeypatch.delenv(k)
+    # against the C oracle, every row
+    if conv == "numpy":
+        want = c_oracle.COracle(problem_from_kwargs(kw)).loglike_batch(P)
+        assert np.abs(ref["logl"] - want).max() < LOGL_ATOL
+    # a wait that runs out (here: a limit of 10 ns, shorter than any PCIe round trip) raises the kernel's status word;
+    # the grid drains, the call fails over to the pipeline and still returns the right bits
+    monkeypatch.setenv("MCALF_STREAM_TIMEOUT", "1e-8")
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        got = fit.loglike_batch(P)
+        assert fit.last_launch().path == _lib.MCALF_PATH_HOST_PIPELINED
+        assert np.array_equal(got, ref["logl"])
+        # ... and the queues were re-armed: with the limit restored the next context streams again
+    monkeypatch.delenv("MCALF_STREAM_TIMEOUT")
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        assert np.array_equal(fit.loglike_batch(P), ref["logl"])
+        assert fit.last_launch().path == _lib.MCALF_PATH_HOST_STREAM
 
 
 @pytest.mark.parametrize("cfg,conv", [("A", "numpy"), ("C", "numpy"), ("E", "numpy"), ("C", "jax"), ("E", "jax")])
