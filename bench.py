@@ -7,8 +7,14 @@ A "step" is one pass of the hot path over one batch of synthetic live points.
                    4 fillers, LSF resolution floated in [8, 9] km/s, CIV doublet, 4000 pixels.
   N > 1 (default)  BASELINE.json config D -- the same problem with 32768 live points job-wide, cut into
                    contiguous row blocks over the N ranks (strong scaling: the job-wide batch is fixed), the
-                   per-sample logL gathered to rank 0 over RCCL every step.  The N = 1 line carries the
-                   one-GPU time of the same 32768 rows (`strong_scaling_reference`).
+                   per-sample logL gathered to rank 0 over RCCL every step.  The gather is timed THREE ways in the
+                   one process group, in this order: torch.distributed.gather (two buffers in flight), the
+                   library's own exchange on the launch stream, the library's exchange on its side stream
+                   (overlap); each leg has its `ms_per_step`, `gather_check` and the ranks' min / max kernel time
+                   under `gathers`, the best one is `value`.  The two library legs run under a watchdog: a leg
+                   that has not finished after 30 s is recorded as "timed_out", the line is printed from what has
+                   been measured and the process exits non-zero.  The N = 1 line carries the one-GPU time of the
+                   same 32768 rows (`strong_scaling_reference`).
 
 `value` is timed through the device-pointer entry, parameters resident in HBM when the timed region starts and
 logL left in HBM (the bench contract).  `value_host_api` is the same K steps through the host-pointer entry
@@ -27,6 +33,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with `hipIpcGetMemHandle: invalid argument`
@@ -205,10 +212,14 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real multi-GPU path) or gloo: a rehearsal of the N>1 control flow on a "
                          "one-GPU box (all ranks share cuda:0, logL shards gathered through host memory)")
-    ap.add_argument("--gather", default="torch", choices=["torch", "inlib"],
-                    help="N>1: torch = torch.distributed.gather of the logL shards (RCCL through torch, depth-2 ring, the "
-                         "default), inlib = the library's own communicator (mcalf_comm_init + mcalf_loglike_gather_device: "
-                         "kernels and one grouped ncclSend/ncclRecv exchange on the launch stream)")
+    ap.add_argument("--gather", default="all", choices=["all", "torch", "inlib", "inlib_overlap"],
+                    help="N>1: which gather of the logL shards is timed.  all (default) = the three of them, one after the "
+                         "other in the one process group, best one reported as `value`: torch = torch.distributed.gather "
+                         "(RCCL through torch, two buffers in flight); inlib = the library's own communicator "
+                         "(mcalf_comm_init + mcalf_loglike_gatherv_device: kernels and one grouped ncclSend/ncclRecv exchange "
+                         "on the launch stream); inlib_overlap = the same with the exchange on the context's side stream")
+    ap.add_argument("--leg-timeout", type=float, default=30.0,
+                    help="N>1: seconds a library-gather leg may take before the watchdog prints what has been measured and exits")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer (PCIe-inclusive) passes")
     ap.add_argument("--no-strong-ref", action="store_true", help="N=1: skip the config-D-on-one-GPU reference")
     ap.add_argument("--no-model-leg", action="store_true", help="N=1: skip the model-output (reconstruct_spec) passes")
@@ -279,11 +290,13 @@ def main():
             _lib.check(f2._lib.mcalf_reserve(f2._ctx, batch), f2._ctx)
             s2 = torch.cuda.Stream()
             extra.append((f2, s2, torch.empty(batch, dtype=torch.float64, device=dev)))
-    inlib = mdist.InLibGather(fit, batch * world, dev) if (use_dist and args.gather == "inlib" and not rehearsal) else None
     turn = [0]
     launch = fit._lib.mcalf_loglike_batch_device
     ctx, pP = fit._ctx, dP.data_ptr()
     last_out = [dlogL]
+    inlib_box = [None]                                   # the library-gather object of the leg that is running
+    gathered = [None]
+    red_dev = "cpu" if rehearsal else dev
 
     def step():
         if extra:
@@ -295,6 +308,7 @@ def main():
                 if rc:
                     _lib.check(rc, f2._ctx)
                 return
+        inlib = inlib_box[0]
         if inlib is not None:
             inlib.step(dP, stream)
             last_out[0] = inlib.local
@@ -309,12 +323,10 @@ def main():
                 plan.local.copy_(dlogL)                  # through host memory (gloo)
             plan.gather_async()                          # RCCL gather of the logL shards to rank 0
 
-    gathered = [None]
-
     def fence():
         if use_dist:
-            if inlib is not None:
-                gathered[0] = inlib.finish(stream)       # joins the exchanges of the library's side stream
+            if inlib_box[0] is not None:
+                gathered[0] = inlib_box[0].finish(stream)    # joins the exchanges of the library's side stream
             else:
                 gathered[0] = plan.finish()              # every outstanding gather has landed on rank 0
             dist.barrier()
@@ -345,33 +357,92 @@ def main():
         times = sorted(float(v) for v in t.tolist())
         return times[len(times) // 2], times
 
-    red_dev = "cpu" if rehearsal else dev
-    for _ in range(args.warmup):
-        step()
-    elapsed, pass_times = measure(step, args.steps, red_dev)
+    def kernel_pass():
+        """Dominant kernel alone: a further pass of K launches, each bracketed by HIP events on the launch stream
+        inside the library (one fused launch per step: the library issues the batch as ONE row block while it is
+        being profiled).  Kept out of the timed region because the brackets themselves cost ~5 us per step."""
+        km, nl = C.c_double(0.0), C.c_int32(0)
+        _lib.check(fit._lib.mcalf_profile_begin(fit._ctx, args.steps), fit._ctx)
+        for _ in range(args.steps):
+            step()
+        fence()
+        _lib.check(fit._lib.mcalf_profile_end(fit._ctx, C.byref(km), C.byref(nl)), fit._ctx)
+        return km.value if nl.value else None
+
+    def run_leg():
+        """Warm-up, timed passes, kernel pass and gather check of the gather that is currently selected."""
+        for _ in range(args.warmup):
+            step()
+        el, passes = measure(step, args.steps, red_dev)
+        own = last_out[0].cpu().numpy().copy()
+        check = None
+        if use_dist and rank == 0 and gathered[0] is not None:
+            # the vector rank 0 holds after the last gather: its own block must be what it computed, and every
+            # other block a finite logL of that rank's rows
+            g = gathered[0].cpu().numpy()
+            check = {"rows": int(g.size), "own_block_equal": bool(np.array_equal(g[:batch], own)),
+                     "all_finite": bool(np.isfinite(g).all())}
+        km = kernel_pass()
+        km = km if km is not None else el / args.steps * 1e3
+        kmin = kmax = km
+        if use_dist:                                     # load imbalance: the ranks' own kernel times
+            kt = torch.tensor([km, -km], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+            kmax, kmin = float(kt[0].item()), -float(kt[1].item())
+        return {"elapsed": el, "pass_times": passes, "logL": own, "gather_check": check, "kernel_ms": km,
+                "kernel_ms_min_over_ranks": kmin, "kernel_ms_max_over_ranks": kmax}
+
+    GATHER_WHAT = {
+        "torch": "torch.distributed.gather, two buffers in flight",
+        "inlib": "library (mcalf_loglike_gatherv_device: kernels and one grouped ncclSend/ncclRecv exchange on the launch stream)",
+        "inlib_overlap": "library (mcalf_loglike_gatherv_device: kernels on the launch stream, grouped ncclSend/ncclRecv on the "
+                         "context's exchange stream, two buffer pairs in flight)",
+    }
+    legs, leg_notes = {}, {}
+    names = ["torch"]
+    if use_dist:
+        names = ["torch", "inlib", "inlib_overlap"] if args.gather == "all" else [args.gather]
+    # the library's exchange needs one RCCL rank per device; a gloo rehearsal on ONE GPU can only drive it over the
+    # tests' stand-in transport (MCALF_RCCL_LIB)
+    can_inlib = use_dist and (not rehearsal or bool(os.environ.get("MCALF_RCCL_LIB")))
+
+    def emit_partial_and_exit(name):
+        """Watchdog of a library-gather leg: print what has been measured, exit non-zero (a fresh exit, never a re-exec)."""
+        leg_notes[name] = "timed_out"
+        if rank == 0:
+            done = {k: {"ms_per_step": v["elapsed"] / args.steps * 1e3, "gather_check": v["gather_check"]} for k, v in legs.items()}
+            best = min(legs, key=lambda k: legs[k]["elapsed"]) if legs else None
+            line = {"metric": "component-pixel Voigt evals/s", "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
+                    "data": "synthetic", "value": (comp_pix * world * args.steps / legs[best]["elapsed"]) if best else None,
+                    "ms_per_step": (legs[best]["elapsed"] / args.steps * 1e3) if best else None,
+                    "gather_reported": best, "gathers": {**done, name: "timed_out"},
+                    "config": {"workload": WORKLOAD_LABEL[config], "batch_per_gpu": batch, "global_batch": batch * world},
+                    "error": f"gather leg {name!r} did not finish within {args.leg_timeout:.0f} s"}
+            print(json.dumps(line), flush=True)
+        os._exit(3)
+
+    for name in names:
+        if name != "torch" and not can_inlib:
+            leg_notes[name] = "skipped: a gloo rehearsal on one GPU has no RCCL transport for the library's exchange"
+            continue
+        watchdog = None
+        if name != "torch":
+            watchdog = threading.Timer(args.leg_timeout, emit_partial_and_exit, args=(name,))
+            watchdog.daemon = True
+            watchdog.start()
+            inlib_box[0] = mdist.InLibGather(fit, batch * world, dev, depth=2 if name == "inlib_overlap" else 1)
+        legs[name] = run_leg()
+        if watchdog is not None:
+            watchdog.cancel()
+    reported = min(legs, key=lambda k: legs[k]["elapsed"])
+    inlib_box[0] = None                                  # (what follows fences through the torch plan again)
+    elapsed, pass_times = legs[reported]["elapsed"], legs[reported]["pass_times"]
+    logL_dev, gather_check, kern_ms = legs[reported]["logL"], legs[reported]["gather_check"], legs[reported]["kernel_ms"]
     tot = torch.tensor([comp_pix, line_pix], dtype=torch.float64, device=red_dev)
     if use_dist:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     comp_pix_job, line_pix_job = (float(v) for v in tot.tolist())
-    logL_dev = (inlib.local if inlib is not None else last_out[0]).cpu().numpy()
-    gather_check = None
-    if use_dist and rank == 0 and gathered[0] is not None:
-        # the vector rank 0 holds after the last gather: its own block must be what it computed, and every
-        # other block a finite logL of that rank's rows
-        g = gathered[0].cpu().numpy()
-        gather_check = {"rows": int(g.size), "own_block_equal": bool(np.array_equal(g[:batch], logL_dev)),
-                        "all_finite": bool(np.isfinite(g).all())}
-
-    # Dominant kernel alone: a further pass of K launches, each bracketed by HIP events on the launch stream
-    # inside the library (one fused launch per step: the library issues the batch as ONE row block while it is
-    # being profiled).  Kept out of the timed region because the brackets themselves cost ~5 us per step.
-    kern_ms, nl = C.c_double(0.0), C.c_int32(0)
-    _lib.check(fit._lib.mcalf_profile_begin(fit._ctx, args.steps), fit._ctx)
-    for _ in range(args.steps):
-        step()
-    fence()
-    _lib.check(fit._lib.mcalf_profile_end(fit._ctx, C.byref(kern_ms), C.byref(nl)), fit._ctx)
-    kern_ms = kern_ms.value if nl.value else elapsed / args.steps * 1e3
 
     # PCIe-inclusive passes through the host-pointer entry (N = 1): pageable numpy arrays as a sampler holds
     # them, then page-locked ones
@@ -381,15 +452,40 @@ def main():
         fit.loglike_batch(P_host, out=out_host)
         t_host, _ = measure(lambda: fit.loglike_batch(P_host, out=out_host), args.steps, red_dev)
         same = bool(np.array_equal(out_host, logL_dev))
+        llh = fit.last_launch()
         P_pin = torch.from_numpy(P_host).pin_memory().numpy()
-        out_pin = torch.empty(batch, dtype=torch.float64).pin_memory().numpy()
+        out_pin = torch.full((batch,), float("nan"), dtype=torch.float64).pin_memory().numpy()
         fit.loglike_batch(P_pin, out=out_pin)
         t_pin, _ = measure(lambda: fit.loglike_batch(P_pin, out=out_pin), args.steps, red_dev)
+        # the same entry with a synchronisation after every step: what a synchronous step costs when nothing moves
+        def dev_sync_step():
+            rc = launch(ctx, pP, batch, last_out[0].data_ptr(), st)
+            if rc:
+                _lib.check(rc, ctx)
+            stream.synchronize()
+        t_dsync, _ = measure(dev_sync_step, args.steps, red_dev)
+        dev_ms = elapsed / args.steps * 1e3
         host_api = {"ms_per_step": t_host / args.steps * 1e3, "value": comp_pix * args.steps / t_host,
                     "ms_per_step_pinned": t_pin / args.steps * 1e3, "value_pinned": comp_pix * args.steps / t_pin,
+                    "host_over_device": t_host / args.steps * 1e3 / dev_ms,
+                    "host_over_device_pinned": t_pin / args.steps * 1e3 / dev_ms,
+                    "ms_per_step_device_entry_synchronised_every_step": t_dsync / args.steps * 1e3,
                     "bit_equal_to_device_entry": same,
-                    "what": "mcalf_loglike_batch: H2D of P [batch][ndim] f64 and D2H of logL [batch] f64 inside every "
-                            "step, one synchronous call per step (SURVEY.md 8(d)); pageable numpy arrays / page-locked arrays"}
+                    "bit_equal_to_device_entry_pinned": bool(np.array_equal(out_pin, logL_dev)),
+                    "path": {_lib.MCALF_PATH_HOST_STREAM: "one streaming launch (MCALF_PATH_HOST_STREAM)",
+                             _lib.MCALF_PATH_HOST_PIPELINED: "row-block pipeline (MCALF_PATH_HOST_PIPELINED)"}.get(llh.path, str(llh.path)),
+                    "stream_setup_workgroups": llh.stream_setup_wgs, "completion_polled": bool(llh.stream_polled),
+                    "what": "mcalf_loglike_batch: P [batch][ndim] f64 from host memory and logL [batch] f64 back to host memory "
+                            "inside every step, one synchronous call per step (SURVEY.md 8(d)); pageable numpy arrays / "
+                            "page-locked arrays.  host_over_device = this step over the device-resident step (`ms_per_step`)"}
+        # latency of ONE theta through the reference's callable (lnlhood_dy), the one-launch variant of small calls
+        th = P_host[0].copy()
+        for _ in range(50):
+            fit.lnlhood_dy(th)
+        t1 = time.perf_counter()
+        for _ in range(500):
+            fit.lnlhood_dy(th)
+        host_api["single_call_us"] = (time.perf_counter() - t1) / 500 * 1e6
 
     # N = 1 leg of the strong-scaling job: config D's 32768 rows on this one GPU
     strong_ref = None
@@ -526,10 +622,25 @@ def main():
                          "lines_per_sync": ll.lines_per_sync, "ordered_handout": bool(ll.ordered)}
         if use_dist:
             out["rccl_ranks"] = rccl_ranks
-            out["gather"] = ("library (mcalf_loglike_gatherv_device: kernels on the launch stream, grouped ncclSend/ncclRecv "
-                             "on the context's exchange stream, two buffer pairs in flight"
-                             + ("; ONE rank: the exchange is a device-to-device copy, no RCCL call is made)" if rccl_ranks == 1 else ")")
-                             if inlib is not None else "torch.distributed.gather, two buffers in flight")
+            out["gather_reported"] = reported
+            out["gather"] = GATHER_WHAT[reported] + ("; ONE rank: the library's exchange is a device-to-device copy, no RCCL call "
+                                                      "is made" if (rccl_ranks == 1 and reported != "torch") else "")
+            # every gather that was timed in this process group, in the order they ran; `value` is the best one
+            out["gathers"] = {}
+            for name in names:
+                if name in legs:
+                    lg = legs[name]
+                    out["gathers"][name] = {
+                        "what": GATHER_WHAT[name], "ms_per_step": lg["elapsed"] / args.steps * 1e3,
+                        "value": comp_pix_job * args.steps / lg["elapsed"], "gather_check": lg["gather_check"],
+                        "kernel_ms_min_over_ranks": lg["kernel_ms_min_over_ranks"],
+                        "kernel_ms_max_over_ranks": lg["kernel_ms_max_over_ranks"],
+                        "passes": len(lg["pass_times"])}
+                else:
+                    out["gathers"][name] = leg_notes.get(name, "not run")
+            if rehearsal:
+                out["gathers_note"] = ("gloo REHEARSAL on one GPU: every rank shares cuda:0; the library legs run over the tests' "
+                                       "stand-in transport when MCALF_RCCL_LIB names it, else they are skipped")
         if args.cpu_seconds > 0 and world == 1:          # the CPU baseline is an N=1 figure (rank 0 only)
             vals, dt, done = cpu_baseline(kw, P_host, args.cpu_seconds)
             k = len(vals)

@@ -837,6 +837,13 @@ __device__ __forceinline__ void stream_exit(const KArgs& a, int tid) {
     if (tid != 0) return;
     stream_stores_done();
     if (atomicAdd(&a.sctl->exited, 1u) == gridDim.x - 1) {
+        unsigned lo = ~0u, hi = 0u;                      // (diagnostic: how evenly the dispatcher spread the grid over the XCDs)
+        for (int k = 0; k < kXcds; ++k) {
+            const unsigned n = __hip_atomic_load(&a.sctl->arrive[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lo = min(lo, n); hi = max(hi, n);
+        }
+        __hip_atomic_store(a.status + 2, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.status + 3, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         for (int k = 0; k < kXcds; ++k) {
             __hip_atomic_store(&a.sctl->arrive[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.sctl->sq_eager[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1537,6 +1544,7 @@ struct mcalf_ctx {
     unsigned int stream_gen = 0;
     int stream_on = 1;                      // MCALF_STREAM=0: the row-block pipeline of round 2 instead
     int stream_wgs = 16;                    // MCALF_STREAM_WGS: workgroups dedicated to the set-up while rows are outstanding
+    int stream_eager = 0;                   // MCALF_STREAM_EAGER: blocks of 8 rows per XCD any workgroup may set up (0: what the first items need)
     int stream_chunk = 32;                  // MCALF_STREAM_CHUNK: rows such a workgroup claims (and copies to HBM) at a time
     int stream_trace = 0;                   // MCALF_STREAM_TRACE=1 (diagnostic): host-side time per phase of the streaming entry
     int stream_device = 0;                  // MCALF_STREAM_DEVICE=1 (diagnostic): the *_device scalar entries take the streaming launch too
@@ -1920,6 +1928,7 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         if (const char* e = std::getenv("MCALF_STREAM")) ctx->stream_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("MCALF_STREAM_WGS")) ctx->stream_wgs = std::min(std::max(std::atoi(e), 1), ctx->num_cu);
         if (const char* e = std::getenv("MCALF_STREAM_POLL")) ctx->stream_poll = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MCALF_STREAM_EAGER")) ctx->stream_eager = std::max(std::atoi(e), 0);
         if (const char* e = std::getenv("MCALF_STREAM_CHUNK")) ctx->stream_chunk = std::min(std::max(std::atoi(e) & ~7, 8), 512);
         if (const char* e = std::getenv("MCALF_STREAM_DEVICE")) ctx->stream_device = std::atoi(e);
         if (const char* e = std::getenv("MCALF_STREAM_TRACE")) ctx->stream_trace = std::atoi(e) != 0;
@@ -2130,8 +2139,9 @@ static int launch_preflight(mcalf_ctx* ctx, int mode, int64_t batch) {
 static void stream_trace_report(const mcalf_ctx* ctx) {
     if (!ctx->stream_trace || g_stream_trace.n == 0) return;
     const double n = (double)g_stream_trace.n;
-    std::fprintf(stderr, "mcalf stream trace (%ld calls, us per call): pointer checks %.2f, prepare %.2f, launch %.2f, stage rows %.2f, "
-                 "wait %.2f, copy out %.2f\n", g_stream_trace.n, g_stream_trace.t[0] / n, g_stream_trace.t[1] / n, g_stream_trace.t[2] / n,
+    std::fprintf(stderr, "mcalf stream trace (%ld calls, us per call; workgroups per XCD in the last launch: %u .. %u): pointer checks %.2f, "
+                 "prepare %.2f, launch %.2f, stage rows %.2f, wait %.2f, copy out %.2f\n", g_stream_trace.n,
+                 ctx->h_ctl ? ctx->h_ctl[2] : 0u, ctx->h_ctl ? ctx->h_ctl[3] : 0u, g_stream_trace.t[0] / n, g_stream_trace.t[1] / n, g_stream_trace.t[2] / n,
                  g_stream_trace.t[3] / n, g_stream_trace.t[4] / n, g_stream_trace.t[5] / n);
     g_stream_trace = StreamTrace();
 }
@@ -2500,7 +2510,8 @@ static int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t ba
     if (trace) tm[2] = now_us();
     // the rows an XCD's first items need are set up by whichever of its workgroups gets there first, the rest by its
     // dedicated workgroups
-    if ((rc = stream_launch(ctx, mode, dP_view, batch, d_out_view, ctx->stream, wgs, (first_rows + 7) / 8, !pin_in, true)))
+    const int64_t eager_blocks = ctx->stream_eager > 0 ? ctx->stream_eager : (first_rows + 7) / 8;
+    if ((rc = stream_launch(ctx, mode, dP_view, batch, d_out_view, ctx->stream, wgs, eager_blocks, !pin_in, true)))
         return rc;
     const bool tiled = (mode == kModeLogL || mode == kModeChi2) && ctx->ntiles > 1;
     if (trace) tm[3] = now_us();

@@ -146,6 +146,13 @@ class InLibGather:
         self.counts = shard_counts(self.batch, self.world)
         self.lo, self.hi = shard_bounds(self.batch, self.world, self.rank)
         self.n = self.hi - self.lo
+        if self.world > 1:
+            # every rank must pass the SAME count vector to mcalf_loglike_gatherv_device (a receive posted for a count
+            # the sender does not send is a hang nothing can detect locally): compare them once, here
+            seen = [None] * self.world
+            dist.all_gather_object(seen, (self.batch, tuple(self.counts)), group=group)
+            if any(v != seen[0] for v in seen):
+                raise ValueError(f"InLibGather: the ranks disagree on the shard counts: {seen}")
         ident = [None]
         if self.rank == self.root:
             buf = C.create_string_buffer(_lib.MCALF_COMM_ID_BYTES)

@@ -104,3 +104,38 @@ def test_argument_errors_return_a_code_and_the_context_destroys_cleanly():
         torch.cuda.synchronize()
         assert np.array_equal(full.cpu().numpy(), want) and np.array_equal(out.cpu().numpy(), want)
         _lib.check(lib.mcalf_comm_destroy(ctx), ctx)
+
+
+def _bench_two_ranks(fake, *extra):
+    env = dict(os.environ, MCALF_RCCL_LIB=fake, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "D",
+           "--batch", "4608", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", *extra]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_n2_times_the_three_gathers_in_one_process_group(fake_rccl):
+    """`bench.py --gpus 2` (gloo rehearsal on the one GPU, the library's exchange over the stand-in transport): the torch
+    gather, the library's exchange on the launch stream and the library's exchange on its side stream are timed one after
+    the other in the ONE process group, each with its gather check and the ranks' kernel times; the best is `value`."""
+    res, out = _bench_two_ranks(fake_rccl)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and list(out["gathers"]) == ["torch", "inlib", "inlib_overlap"]
+    for name, g in out["gathers"].items():
+        assert isinstance(g, dict), (name, g)
+        assert g["gather_check"] == {"rows": 4608, "own_block_equal": True, "all_finite": True}, name
+        assert g["ms_per_step"] > 0 and 0 < g["kernel_ms_min_over_ranks"] <= g["kernel_ms_max_over_ranks"]
+    best = min(out["gathers"], key=lambda k: out["gathers"][k]["ms_per_step"])
+    assert out["gather_reported"] == best and out["ms_per_step"] == pytest.approx(out["gathers"][best]["ms_per_step"])
+    assert out["value"] == pytest.approx(out["gathers"][best]["value"])
+
+
+def test_bench_watchdog_prints_what_was_measured_and_exits_nonzero(fake_rccl):
+    """A library-gather leg that does not finish in time (here: a limit no leg can meet) is recorded as "timed_out"; the
+    line carries the torch leg that was already measured; the process exits non-zero -- nobody waits for a hung rank."""
+    res, out = _bench_two_ranks(fake_rccl, "--leg-timeout", "0.0001")
+    assert res.returncode != 0
+    assert out is not None and out["gathers"]["inlib"] == "timed_out" and out["gather_reported"] == "torch"
+    assert out["gathers"]["torch"]["gather_check"]["own_block_equal"] is True and "did not finish" in out["error"]

@@ -183,3 +183,10 @@ def test_two_rank_job_through_the_product_path_on_one_gpu():
     assert out["config"]["batch_per_gpu"] == 1024 and out["config"]["global_batch"] == 2048
     assert out["gather_check"] == {"rows": 2048, "own_block_equal": True, "all_finite": True}
     assert out["parity"]["max_abs_dlogL_vs_oracle"] < LOGL_ATOL
+    # the three gathers of the N > 1 line: torch's is timed; without a transport for the library's exchange (one GPU, no
+    # stand-in named) the two library legs say so instead of running
+    assert out["gather_reported"] == "torch" and list(out["gathers"]) == ["torch", "inlib", "inlib_overlap"]
+    g = out["gathers"]["torch"]
+    assert g["gather_check"] == out["gather_check"] and g["ms_per_step"] == pytest.approx(out["ms_per_step"])
+    assert 0 < g["kernel_ms_min_over_ranks"] <= g["kernel_ms_max_over_ranks"]
+    assert all(isinstance(out["gathers"][k], str) and out["gathers"][k].startswith("skipped") for k in ("inlib", "inlib_overlap"))

@@ -58,6 +58,56 @@ def test_one_persistent_launch_over_the_full_batch_against_both_oracles(cfg):
     assert np.abs(got[idx] - want).max() < LOGL_ATOL
 
 
+def test_config_e_per_gpu_shard_through_the_device_entry_against_both_oracles():
+    """BASELINE config E's share of ONE GPU at N = 8 -- rows 0 .. 2047 of the 16384 of `default_rng(4)` (contiguous row
+    blocks, rank 0's) -- through `mcalf_loglike_batch_device`: one persistent launch over 2048 x 5 pixel tiles (multi-tile
+    instantiation, no ordered hand-out), the finalize kernel behind it; every row against the C oracle, a spread against
+    the numpy / scipy oracle (damped Ly-alpha wings: the wide-wing Faddeeva regime)."""
+    kw, batch, seed = workloads.config("E", oracle_synth)
+    assert (batch, seed) == (16384, 4)
+    P = workloads.draw_P(kw, batch, np.random.default_rng(seed), damped=2)[:2048].copy()
+    n = P.shape[0]
+    prob = problem_from_kwargs(kw)
+    dP = torch.from_numpy(P).cuda()
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        got = _device_logl(fit, dP, n)
+        ll = fit.last_launch()
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        assert fit.info.ntiles == 5
+        assert (ll.path, ll.row_blocks, ll.persistent, ll.grid, ll.items) == (_lib.MCALF_PATH_DEVICE, 1, 1, 2 * cus, 5 * n)
+        assert (ll.selfhalo, ll.ordered, ll.inline_setup) == (0, 0, 0)
+    assert np.isfinite(got).all()
+    want_c = c_oracle.COracle(prob, threads=min(16, os.cpu_count() or 1)).loglike_batch(P)      # EVERY row
+    assert np.abs(got - want_c).max() < LOGL_ATOL
+    assert (np.abs(got - want_c) / np.abs(want_c)).max() < 1e-10
+    idx = np.arange(0, n, n // 16)
+    assert np.abs(got[idx] - o.loglike_batch(prob, P[idx])).max() < LOGL_ATOL
+
+
+def test_jax_semantics_persistent_launch_against_the_f64_restatement():
+    """conv_mode='jax' (hires_fitter.py:521-695: fixed kernel grid, zero padding, edge reset, floor on the ncomp slot) on
+    config C with 2600 rows through the device entry -- the persistent `<true, ...>` instantiation a vectorised jaxns
+    batch would run -- against `jax_loglike_f64` on a spread of 64 rows; and bit-equal to the same rows evaluated as
+    small calls (the one-launch variant)."""
+    kw, _, seed = workloads.config("C", oracle_synth)
+    kw = dict(kw, conv_mode="jax")
+    n = 2600
+    P = workloads.draw_P(kw, n, np.random.default_rng(seed + 41))
+    prob = problem_from_kwargs(kw)
+    dP = torch.from_numpy(P).cuda()
+    idx = np.arange(0, n, n // 64)[:64]
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        got = _device_logl(fit, dP, n)
+        ll = fit.last_launch()
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        assert (ll.path, ll.persistent, ll.grid, ll.items, ll.inline_setup) == (_lib.MCALF_PATH_DEVICE, 1, 2 * cus, n, 0)
+        small = fit.loglike_batch(P[idx])
+        assert fit.last_launch().inline_setup == 1
+    want = np.array([o.jax_loglike_f64(prob, p) for p in P[idx]])
+    assert np.abs(got[idx] - want).max() < LOGL_ATOL
+    assert np.array_equal(got[idx], small)
+
+
 def test_persistent_switch_is_really_taken_and_changes_nothing(monkeypatch):
     """MCALF_PERSIST / MCALF_ORDER / MCALF_LINES_PER_SYNC are scheduling choices.  The mode is read back from the
     library for every context (device entry, >= 4 items per workgroup slot so that the persistent grid applies)."""
