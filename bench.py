@@ -157,7 +157,7 @@ def stamped(entry, lib_hash):
     have = entry.get("source_hash")
     if have != lib_hash or lib_hash == "unstamped":
         return None, (f"profiles/ record was measured on kernel sources {have}, the loaded library is {lib_hash}: "
-                      "stale counters are not quoted (re-run tools/r03_profiles.sh)")
+                      "stale counters are not quoted (re-run tools/profiles.sh)")
     return entry, None
 
 
@@ -599,7 +599,9 @@ def main():
                               "pmc_note": pmc_note},
         }
         if pmc:
-            out["roofline_valu"].update({k: pmc[k] for k in ("valu_busy", "executed_flops_per_launch", "source") if k in pmc})
+            out["roofline_valu"].update({k: pmc[k] for k in ("valu_busy", "executed_flops_per_launch", "executed_flops_note",
+                                                             "valu_active_lane_fraction", "executed_flops_lane_weighted_estimate",
+                                                             "source") if k in pmc})
             if "executed_flops_per_launch" in pmc:
                 ex = pmc["executed_flops_per_launch"] / (kern_ms * 1e-3) / 1e12
                 out["roofline_valu"].update({"achieved": ex, "frac": ex / FP64_VALU_PEAK_TFLOPS})

@@ -54,13 +54,7 @@ static_assert(VT_NTOT <= kBlock - 64 && (kZ0Lds % 2) == 0 && (kZFLds % 2) == 0 &
 constexpr int kRedDoubles = 3 * kWaves + 2;   // per-wave partials (sum, count, scratch) + the next work-item index
 constexpr int kTileSlack = 16;           // zero-filled entries past the halo (sliding-window over-read)
 constexpr size_t kLdsBudget = 78 * 1024;   // two workgroups per CU (160 KiB); needs the MaxDynamicSharedMemorySize attribute
-#ifndef MCALF_FAR_INTERP
-#define MCALF_FAR_INTERP 1
-#endif
-constexpr bool kFarInterp = MCALF_FAR_INTERP != 0;
-#ifndef MCALF_BALANCE_PRIO
-#define MCALF_BALANCE_PRIO 1      // progress-based wave priority in the component loop (measured -3.5 % at config B)
-#endif
+constexpr bool kFarInterp = true;          // far wings at 8 nodes per 64-pixel segment (tools/interp_check.py builds the other variant)
 constexpr double kInterpC = 1.0e-3;        // interpolation error <= kInterpC (du/u0)^8 (measured 4.4e-4, tools/ + DESIGN.md)
 constexpr double kInterpTol = 1.0e-15;     // allowed optical-depth error per (line, pixel) from the interpolation
 constexpr double kCcgs = 2.9979245e10;  // hires_fitter.py:66
@@ -303,16 +297,6 @@ __device__ inline void build_line_record(double* rec, double logN, double z, dou
     }
 }
 
-#ifdef MCALF_STAMPS   // diagnostic builds only (tools/): per-work-item phase timestamps (`w` = the item index in scope)
-__device__ unsigned long long g_stamps[8192 * 8];
-__device__ unsigned long long g_dbg[4];   // [0] interpolated segments, [1] segments seen
-#define MCALF_STAMP(k) do { if (threadIdx.x == 0 && w < 8192) g_stamps[w * 8 + (k)] = ((k) == 0 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
-#define MCALF_STAMP_SLOT(k) do { if (threadIdx.x == 0 && w < 8192) g_stamps[w * 8 + (k)] = blockIdx.x; } while (0)
-#else
-#define MCALF_STAMP(k) do { } while (0)
-#define MCALF_STAMP_SLOT(k) do { } while (0)
-#endif
-
 // acc += a * b and acc += a with the accumulator tied to its register: without the tie the compiler
 // gives every update of the thread's 8 running optical depths a fresh register and copies all of them
 // back at the loop back-edge (16 v_mov_b64 per line).
@@ -353,9 +337,6 @@ __device__ __forceinline__ void eval_line(const double* __restrict__ tab,
         mp &= mp >> 7;                                        // bit 8j = first and last node
         mn &= mn >> 7;
         done = uniform64((mp | mn) & segOk);                 // (segOk carries bits 8j only, so `done` does too)
-#ifdef MCALF_COUNT_INTERP
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&g_dbg[0], (unsigned long long)__popcll(done)); atomicAdd(&g_dbg[1], 8ULL); atomicAdd(&g_dbg[2], (unsigned long long)__popcll(segOk)); }
-#endif
         if (done != 0) {                                      // wave-uniform
             // byte j -> 0xFF: one bit per lane.  On 32-bit halves (no carry can cross: 0x01010101 * 0xFF = 0xFFFFFFFF),
             // which is two scalar multiplies instead of a 64-bit one.
@@ -539,11 +520,7 @@ __device__ __forceinline__ void setup_sample(const KArgs& a, long s, int lane, d
     const int nTargetSlots = (a.mode == kModeOneComp) ? nl_eff : a.ncompmax * a.nlines;
     const int nSlots = nTargetSlots + ((a.mode == kModeOneComp) ? 0 : a.nfill);
     int ngenLane = 0;
-#if defined(MCALF_ABL_SETUP) && (MCALF_ABL_SETUP & 2)   // ablation builds only (tools/): no records
-    for (int slot = lane; slot < 0; slot += 64) {
-#else
     for (int slot = lane; slot < nSlots; slot += 64) {
-#endif
         double logN, z, b;
         const LineDev* ln;
         int dst;                                    // index in the compacted record list, -1: inactive
@@ -595,11 +572,7 @@ __device__ __forceinline__ void setup_sample(const KArgs& a, long s, int lane, d
     const double inv2s2 = kZeroPad ? 1.0 / (2.0 * sigma * sigma) : 0.5 / (sigma * sigma);
     const double amp = kZeroPad ? 1.0 : 1.0 / (sqrt(2.0 * M_PI) * sigma);          // Gaussian1DKernel amplitude
     double wsum = 0.0, botOrdered = 0.0;
-#if defined(MCALF_ABL_SETUP) && (MCALF_ABL_SETUP & 1)   // ablation builds only (tools/): no taps
-    if (false) {
-#else
     if (ntap8 <= 64) {                               // the usual case: one tap per lane, one exp
-#endif
         const double dk = (double)(lane - n);
         const double g = (lane > 2 * n) ? 0.0 : ((n == 0 && !kZeroPad) ? 1.0 : exp_neg((dk * dk) * inv2s2) * amp);
         const double gsum = wave_allsum(g);
@@ -615,11 +588,7 @@ __device__ __forceinline__ void setup_sample(const KArgs& a, long s, int lane, d
                 botOrdered += __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
             }
         }
-    } else
-#if defined(MCALF_ABL_SETUP) && (MCALF_ABL_SETUP & 1)
-    if (false)
-#endif
-    {
+    } else {
         double gsum = 0.0;
         for (int k = lane; k <= 2 * n; k += 64) {
             const double dk = (double)(k - n);
@@ -638,13 +607,8 @@ __device__ __forceinline__ void setup_sample(const KArgs& a, long s, int lane, d
                 botOrdered += exp_neg((dk * dk) * inv2s2) * amp / gsum;
             }
     }
-#if defined(MCALF_ABL_SETUP) && (MCALF_ABL_SETUP & 1)
-    const double bot = 1.0;
-    const int ngen = 0;
-#else
     const double bot = kZeroPad ? 1.0 : botOrdered;
     const int ngen = ngenLane;
-#endif
     if (lane == 0) {
         SampleHdr h;
         h.cont = cont; h.bot = bot; h.ncl = ncl; h.n = n; h.bad = bad ? 1 : 0; h.ngeneral = ngen;
@@ -856,9 +820,7 @@ __device__ __forceinline__ void stream_exit(const KArgs& a, int tid) {
     }
 }
 
-#ifndef MCALF_MIN_WAVES
-#define MCALF_MIN_WAVES 4
-#endif
+constexpr int kMinWaves = 4;            // waves per SIMD the fused kernel is compiled for (2 workgroups of 8 waves per CU)
 // Everything the next work item needs from global memory, requested while the current item is still in its
 // convolution / likelihood phase (the loads then have the whole reduction to land in).
 struct ItemLoads {
@@ -999,7 +961,6 @@ __device__ __forceinline__ void fused_items(const KArgs& a, double* smem) {
     request_item<kZeroPad, kSelfHalo, kInline, kStream>(a, w, tid0, L);
 
     while (true) {
-        MCALF_STAMP(0);
         // Per item the thread index passes through an empty asm: everything derived from it (LDS offsets, tile
         // positions, global addresses -- dozens of registers) is then formed where it is used instead of being
         // hoisted out of the item loop and kept alive through the component loop, which sits at the kernel's
@@ -1087,7 +1048,6 @@ __device__ __forceinline__ void fused_items(const KArgs& a, double* smem) {
             } else { sNext[0] = tHeld; sNext[1] = tHeld; }
         }
 
-        MCALF_STAMP(1);
         // ---- 2. tau for this thread's pixels ----------------------------------------------------
         __syncthreads();                                   // publishes sRec, sW, sT, sNext (and the header of the one-launch variant)
         if (kInline) hd = *sHdr;
@@ -1101,24 +1061,17 @@ __device__ __forceinline__ void fused_items(const KArgs& a, double* smem) {
             tNext = __builtin_amdgcn_readfirstlane(sNext[0]);            // the next ticket ...
             wNext = __builtin_amdgcn_readfirstlane(sNext[1]);            // ... and the work item it stands for
         }
-        MCALF_STAMP(2);
         int buf = 0;
-#ifdef MCALF_ABL_NOLOOP   // ablation builds only (tools/); never defined in the product build
-        const int ncl_run = 0;
-#else
         const int ncl_run = ncl;
-#endif
         // kLinesPerSync lines are folded per workgroup barrier (their tables are double-buffered), which
         // halves the barriers and averages the per-wave core/wing imbalance over more work.
         for (int cl0 = 0; cl0 < ncl_run; cl0 += kLinesPerSync) {
-#if MCALF_BALANCE_PRIO
             // Wave priority falls as the workgroup progresses, so of the two workgroups sharing a CU the one
-            // that is behind gets the issue slots.
+            // that is behind gets the issue slots (measured -3.5 % at config B).
             if (4 * cl0 < ncl_run) __builtin_amdgcn_s_setprio(3);
             else if (4 * cl0 < 2 * ncl_run) __builtin_amdgcn_s_setprio(2);
             else if (4 * cl0 < 3 * ncl_run) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
-#endif
             double* tabs = sTab + buf * (kLinesPerSync * kTabPad);
             if (hasCoef) {
                 double Tn[VT_NY];
@@ -1160,10 +1113,7 @@ __device__ __forceinline__ void fused_items(const KArgs& a, double* smem) {
             for (int l = 0; l < lmax; ++l) eval_line(tabs + l * kTabPad, nu, tau, nuNode, farNode, segOk);
         }
         if (hd.ngeneral > 0 && ncl_run > 0) eval_general_lines(sRec, ncl, nu, tau);
-        MCALF_STAMP(3);
-#if MCALF_BALANCE_PRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
         // Interpolate the far-wing node sums to the pixels (tau[j] += sum_k W[lane][k] F[segment j][node k]),
         // then flux = exp(-tau) into the LDS tile.  The node sums travel through the (now dead) folded-table
         // region, one 64-entry row per wave; the tile holds only the sample's own halo n (<= n_cap).
@@ -1238,7 +1188,6 @@ __device__ __forceinline__ void fused_items(const KArgs& a, double* smem) {
         unsigned stampNext = 0u;
         if (kStream) stampNext = (unsigned)__builtin_amdgcn_readfirstlane(sNext[2]);
 
-        MCALF_STAMP(4);
         // ---- 3+4. convolution, continuum, likelihood terms -------------------------------------
         // Register sliding window: this thread owns outputs base..base+7; per tap one new flux value
         // and one (broadcast) weight are read from LDS for eight FMAs.
@@ -1340,7 +1289,6 @@ __device__ __forceinline__ void fused_items(const KArgs& a, double* smem) {
             }
         }
         const bool more = tNext < nItems;
-        MCALF_STAMP(5);
         // The next item's global loads go out here (the pixel data of this item are consumed, so the registers
         // are free): they land while the reduction and the barrier that ends the item run.
         __builtin_amdgcn_sched_barrier(0);
@@ -1370,8 +1318,6 @@ __device__ __forceinline__ void fused_items(const KArgs& a, double* smem) {
             // LSF wider than the provisioned halo: the model was not computed (the reference would build a longer
             // kernel); the row must not look like a valid likelihood -> logL = -inf, chi2 = +inf
             if (bad) { ssum = INFINITY; scnt = 1.0; }
-            MCALF_STAMP_SLOT(6);                         // (diagnostic builds: which workgroup slot ran the item)
-            MCALF_STAMP(7);
             if (a.ntiles == 1) {
                 const double val = finalize_value(a.mode, ssum, scnt, a.asymm != 0, t4, t5, a.veto4, a.veto5);
                 // (streaming launch: the result goes to page-locked host memory and the host reads it as soon as the
@@ -1391,7 +1337,7 @@ __device__ __forceinline__ void fused_items(const KArgs& a, double* smem) {
 }
 
 template <bool kZeroPad, bool kSelfHalo, int kLinesPerSync, bool kInline, bool kStream>
-__global__ __launch_bounds__(kBlock, MCALF_MIN_WAVES) void mcalf_fused_kernel(const KArgs a) {
+__global__ __launch_bounds__(kBlock, kMinWaves) void mcalf_fused_kernel(const KArgs a) {
     static_assert(!(kInline && kStream), "the one-launch variant of small calls has no queue to stream through");
     extern __shared__ __align__(16) double smem[];
     if constexpr (kStream) {
@@ -2985,12 +2931,3 @@ extern "C" int mcalf_voigt_hjerting(const double* x, const double* y, int64_t n,
 extern "C" int mcalf_voigt_hjerting_nodes(const double* x, const double* y, int64_t n, double* out, int32_t device) {
     return hjerting_impl(x, y, n, out, device, 1);
 }
-
-#ifdef MCALF_STAMPS
-extern "C" int mcalf_diag_read_stamps(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_stamps), (size_t)n * sizeof(unsigned long long));
-}
-extern "C" int mcalf_diag_read_dbg(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_dbg), 4 * sizeof(unsigned long long));
-}
-#endif

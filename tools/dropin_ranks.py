@@ -4,9 +4,12 @@ unchanged"): R processes -- PolyChord's MPI workers, cli.py:37-41,110 -- each wi
 ONE GPU of a box, each calling `lnlhood_pc(theta)` serially, one theta per call.  Reports per-call latency and the
 aggregate logL/s for every R, with a parity check (oracle) and a cross-process bit-equality check in every run.
 
-    python tools/dropin_ranks.py [--config B] [--ranks 1,2,4,6] [--calls 2000] [--out profiles/r03_dropin.json]
+    python tools/dropin_ranks.py [--config B] [--ranks 1,2,4,6,6x2,6x4] [--calls 2000] [--out profiles/r04_dropin.json]
 
-The parent never touches the GPU (a GPU box admits at most 6 processes on its card at once)."""
+The parent never touches the GPU (a GPU box admits at most 6 processes on its card at once).  `PxT` = P processes with T
+solver threads each, every thread with its OWN context (ctypes releases the GIL for the duration of the library call):
+the way to put more than six contexts on the card of a box -- the GPU sees P x T independent streams of one-theta
+calls, the host side of a process serialises its threads' few microseconds of Python per call."""
 import argparse
 import json
 import os
@@ -55,11 +58,65 @@ def worker(cfg, rank, nranks, calls, work):
         json.dump(res, fh)
 
 
-def run(cfg, nranks, calls):
+def worker_threads(cfg, rank, nranks, calls, work, nthreads):
+    """`nthreads` solver threads in this process, one context each; the process reports their sum."""
+    import threading
+    import numpy as np
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import mcalf_amd
+    from mcalf_amd import workloads
+    from cases import oracle_synth, problem_from_kwargs
+    from oracle import numpy_oracle as orc
+
+    kw, _, seed = workloads.config(cfg, oracle_synth)
+    common = workloads.draw_P(kw, 32, np.random.default_rng(seed + 1000), damped=2 if cfg == "E" else 0)
+    fits = [mcalf_amd.als_fitter(None, **kw) for _ in range(nthreads)]
+    owns = [workloads.draw_P(kw, calls, np.random.default_rng(seed + 2000 + rank * 64 + t), damped=2 if cfg == "E" else 0)
+            for t in range(nthreads)]
+    for f, own in zip(fits, owns):
+        for p in own[:50]:
+            f.lnlhood_pc(p)
+    open(os.path.join(work, f"ready{rank}"), "w").close()
+    t0 = time.time()
+    while not os.path.exists(os.path.join(work, "go")):
+        assert time.time() - t0 < 120
+        time.sleep(0.0005)
+    lats = [np.empty(calls) for _ in range(nthreads)]
+    walls = [0.0] * nthreads
+
+    def loop(t):
+        f, own, lat = fits[t], owns[t], lats[t]
+        tb = time.perf_counter()
+        for i, p in enumerate(own):
+            t1 = time.perf_counter()
+            f.lnlhood_pc(p)
+            lat[i] = time.perf_counter() - t1
+        walls[t] = time.perf_counter() - tb
+    th = [threading.Thread(target=loop, args=(t,)) for t in range(nthreads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    shared = [fits[0].lnlhood_pc(p)[0] for p in common]
+    same_in_proc = all([f.lnlhood_pc(p)[0] for p in common] == shared for f in fits[1:])
+    prob = problem_from_kwargs(kw)
+    want = np.array([orc.lnlhood_worker(prob, p) for p in common[:8]])
+    lat = np.concatenate(lats)
+    res = {"rank": rank, "calls": calls * nthreads, "wall_s": max(walls), "us_mean": float(lat.mean() * 1e6),
+           "us_median": float(np.median(lat) * 1e6), "us_p99": float(np.percentile(lat, 99) * 1e6), "shared_logL": shared,
+           "threads_bit_equal": bool(same_in_proc),
+           "max_abs_dlogL_vs_oracle": float(np.abs(np.array(shared[:8]) - want).max())}
+    for f in fits:
+        f.close()
+    with open(os.path.join(work, f"res{rank}.json"), "w") as fh:
+        json.dump(res, fh)
+
+
+def run(cfg, nranks, calls, nthreads=1):
     work = tempfile.mkdtemp(prefix="mcalf_dropin_")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", cfg, str(r), str(nranks), str(calls), work],
-                              env=env) for r in range(nranks)]
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", cfg, str(r), str(nranks), str(calls), work,
+                               str(nthreads)], env=env) for r in range(nranks)]
     t0 = time.time()
     while not all(os.path.exists(os.path.join(work, f"ready{r}")) for r in range(nranks)):
         if time.time() - t0 > 300 or any(p.poll() not in (None, 0) for p in procs):
@@ -72,8 +129,8 @@ def run(cfg, nranks, calls):
         if p.wait(timeout=600) != 0:
             raise SystemExit("a worker failed")
     res = [json.load(open(os.path.join(work, f"res{r}.json"))) for r in range(nranks)]
-    same = all(r["shared_logL"] == res[0]["shared_logL"] for r in res)
-    return {"ranks": nranks, "calls_per_rank": calls,
+    same = all(r["shared_logL"] == res[0]["shared_logL"] and r.get("threads_bit_equal", True) for r in res)
+    return {"ranks": nranks * nthreads, "processes": nranks, "threads_per_process": nthreads, "calls_per_rank": calls,
             "aggregate_logL_per_s": sum(r["calls"] / r["wall_s"] for r in res),
             "us_per_call_mean": sum(r["us_mean"] for r in res) / nranks,
             "us_per_call_median": sorted(r["us_median"] for r in res)[nranks // 2],
@@ -84,7 +141,11 @@ def run(cfg, nranks, calls):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--worker":
-        worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6])
+        nthr = int(sys.argv[7]) if len(sys.argv) > 7 else 1
+        if nthr > 1:
+            worker_threads(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], nthr)
+        else:
+            worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6])
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="B")
@@ -92,15 +153,18 @@ def main():
     ap.add_argument("--calls", type=int, default=2000)
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
-    rows = [run(args.config, int(r), args.calls) for r in args.ranks.split(",")]
+    rows = []
+    for spec in args.ranks.split(","):
+        pr, _, thr = spec.partition("x")
+        rows.append(run(args.config, int(pr), args.calls, int(thr) if thr else 1))
     ref = rows[0]["shared_logL_rank0"]
     out = {"what": "R solver ranks, one als_fitter context each on ONE MI355X, lnlhood_pc(theta) one theta per call "
                    "(PolyChord's MPI workers, cli.py:37-41,110)", "config": args.config, "runs": rows,
            "bit_equal_across_runs": all(r["shared_logL_rank0"] == ref for r in rows)}
     for r in rows:
         del r["shared_logL_rank0"]
-        print("R = %d: %.1f us per call (median %.1f, worst p99 %.1f), %.0f logL/s aggregate, bit-equal %s, |dlogL| vs oracle %.1e"
-              % (r["ranks"], r["us_per_call_mean"], r["us_per_call_median"], r["us_per_call_p99_max"], r["aggregate_logL_per_s"],
+        print("R = %d (%d processes x %d threads): %.1f us per call (median %.1f, worst p99 %.1f), %.0f logL/s aggregate, bit-equal %s, |dlogL| vs oracle %.1e"
+              % (r["ranks"], r["processes"], r["threads_per_process"], r["us_per_call_mean"], r["us_per_call_median"], r["us_per_call_p99_max"], r["aggregate_logL_per_s"],
                  r["bit_equal_across_ranks"], r["max_abs_dlogL_vs_oracle"]))
     if args.out:
         with open(args.out, "w") as fh:

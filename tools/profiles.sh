@@ -1,8 +1,10 @@
 #!/bin/bash
-# Round-3 measurement set for one BASELINE config on ONE lease (GPU box): the bench line, the rocprofv3 kernel summary
-# of the same command (one fused launch per step), the PMC passes (each --pmc set its own run, no trace domains), the
-# instruction-issue micro-benchmark.  Usage: tools/r03_profiles.sh <config> <outdir> [steps]
-cfg=${1:-C}; out=${2:-gpurun_out/r03_prof_$cfg}; steps=${3:-50}
+# Measurement set for one BASELINE config on ONE lease (GPU box): the bench line, the rocprofv3 kernel summary of the same
+# command (one fused launch per step), the PMC passes (each --pmc set its own run, no trace domains), the
+# instruction-issue micro-benchmark; then the figures are merged into profiles/pmc.json / traffic.json (stamped with the
+# kernel-source hash) and the bench line is taken AGAIN, now carrying them (bench_with_counters.json).
+# Usage: tools/profiles.sh <config> <outdir> [steps] [round tag, default r04]
+cfg=${1:-C}; out=${2:-gpurun_out/prof_$cfg}; steps=${3:-50}; tag=${4:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
 timeout -k 10 600 python bench.py --config $cfg --steps $steps > "$out/bench.json" 2> "$out/bench.err" || echo "bench failed"
@@ -18,5 +20,10 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --pmc $set -d "$out/pmc$i" --output-format csv -- python3 bench.py $common > "$out/pmc$i.json" 2> "$out/pmc$i.err" || echo "pmc pass $i failed"
 done
+[ -x build/issue_rate ] || hipcc -O3 --offload-arch=gfx950 -o build/issue_rate tools/micro/issue_rate.hip 2>/dev/null
 [ -x build/issue_rate ] && timeout -k 10 120 build/issue_rate > "$out/issue_rate.json" 2> "$out/issue_rate.err"
-python3 tools/r03_profiles_summary.py "$cfg" "$out"
+python3 tools/profiles_summary.py "$cfg" "$out"
+python3 tools/collect_profiles.py --round $tag --src "$out" $cfg
+timeout -k 10 600 python bench.py --config $cfg --steps $steps > "$out/bench_with_counters.json" 2> "$out/bench_with_counters.err" || echo "second bench failed"
+cp "$out/bench_with_counters.json" profiles/${tag}_bench_${cfg}_with_counters.json
+mkdir -p gpurun_out/profiles_${tag}; cp profiles/${tag}_* profiles/pmc.json profiles/traffic.json gpurun_out/profiles_${tag}/ 2>/dev/null

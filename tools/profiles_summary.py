@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise one tools/r03_profiles.sh output directory: per-counter means over the FULL-batch dispatches of the
+"""Summarise one tools/profiles.sh output directory: per-counter means over the FULL-batch dispatches of the
 fused kernel (smaller launches are dropped by grid size), VALU busy, executed FP64 flops, HBM traffic per launch
 (FETCH_SIZE doubled: gfx950 reports half the bytes of coalesced reads, MI355X_MICROARCH.md), the wave-instruction
 counts by class for the issue model -- all stamped with the hash of the kernel sources the library was built from."""
@@ -41,7 +41,14 @@ f64 = None
 if g("SQ_INSTS_VALU_FMA_F64") is not None:
     f64 = g("SQ_INSTS_VALU_FMA_F64") + (g("SQ_INSTS_VALU_MUL_F64") or 0) + (g("SQ_INSTS_VALU_ADD_F64") or 0) + (g("SQ_INSTS_VALU_TRANS_F64") or 0)
     res["executed_flops_per_launch"] = 64.0 * (f64 + g("SQ_INSTS_VALU_FMA_F64"))
-    res["executed_flops_note"] = "64 lanes x (2 FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) wave instructions (exec masks ignored: upper bound)"
+    res["executed_flops_note"] = ("64 lanes x (2 FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) wave instructions: an UPPER BOUND -- exec masks "
+                                  "are ignored (a wave instruction counts 64 lanes whether 1 or 64 of them are enabled)")
+    if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
+        # thread-cycles of VALU work over (busy quad-cycles x 4 cycles x 64 lanes): the share of lanes enabled while the
+        # vector pipe was busy, over ALL vector instructions (not only the FP64 ones)
+        lane = g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 4.0 * 64.0)
+        res["valu_active_lane_fraction"] = lane
+        res["executed_flops_lane_weighted_estimate"] = res["executed_flops_per_launch"] * min(lane, 1.0)
 if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
     res["fetch_size_kib_raw"], res["write_size_kib"] = g("FETCH_SIZE"), g("WRITE_SIZE")
     res["traffic_bytes_per_launch"] = (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024
@@ -64,7 +71,7 @@ if rate and f64 is not None and g("SQ_INSTS_VALU") and g("SQ_INSTS_LDS") is not 
                     "source": "tools/micro/issue_rate.hip on the same lease"}
     # (the branch instructions are part of SQ_INSTS_SALU: remove them from `salu` so that every instruction is priced once)
     insts["salu"] = max(0.0, scalar - insts["branch"])
-res["source"] = "tools/r03_profiles.sh %s (rocprofv3 --pmc, one counter set per run, full-batch mcalf_fused_kernel dispatches)" % cfg
+res["source"] = "tools/profiles.sh %s (rocprofv3 --pmc, one counter set per run, full-batch mcalf_fused_kernel dispatches)" % cfg
 json.dump(res, open(out + "/pmc.json", "w"), indent=1)
 print(json.dumps(res))
 try:

@@ -25,7 +25,15 @@ for cfg in (sys.argv[1:] or ["A", "B", "E"]):
         t0 = time.perf_counter()
         for p in P:
             fit.lnlhood_dy(p)
+        dt_first = (time.perf_counter() - t0) / len(P)       # the process's first few hundred calls (round 3 reported this one)
+        for _ in range(8):                                   # ~2000 more calls: the clocks of an idle GPU take that long to come up
+            for p in P:
+                fit.lnlhood_dy(p)
+        t0 = time.perf_counter()
+        for p in P:
+            fit.lnlhood_dy(p)
         dt = (time.perf_counter() - t0) / len(P)
+        print("config %s: lnlhood_dy %.1f us per call over the context's FIRST %d calls, %.1f us after 2000 more" % (cfg, dt_first * 1e6, len(P), dt * 1e6))
         for b in (1, 8, 64):
             fit.loglike_batch(P[:b])
             t1 = time.perf_counter()

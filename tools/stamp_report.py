@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-workgroup phase timestamps of the fused kernel (needs a -DMCALF_STAMPS build:
+"""Diagnostic: per-workgroup phase timestamps of the fused kernel (needs the instrumented build of tools/make_acc_build.py:
 MCALF_HIP_LIB=build/abl/stamps.so python tools/stamp_report.py)."""
 import ctypes as C
 import os

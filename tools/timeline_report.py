@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: timeline of ONE persistent launch of the fused kernel (needs a -DMCALF_STAMPS build:
+"""Diagnostic: timeline of ONE persistent launch of the fused kernel (needs the instrumented build of tools/make_acc_build.py:
 MCALF_HIP_LIB=build/abl/stamps.so python tools/timeline_report.py C 4096).  Every work item leaves its start and end
 (s_memrealtime, 100 MHz) and the workgroup slot that ran it; from these: ramp, tail, idle share of the slots, the
 spread of item durations, how many items each slot took."""
