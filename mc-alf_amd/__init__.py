@@ -7,6 +7,7 @@ repository root) resolves to this package.
 """
 from . import _lib  # noqa: F401
 from . import adapters  # noqa: F401
+from . import broker  # noqa: F401
 from . import dist  # noqa: F401
 from . import routines  # noqa: F401
 from . import workloads  # noqa: F401

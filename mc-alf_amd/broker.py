@@ -1,0 +1,196 @@
+"""Drop-in mode for MANY solver ranks on one GPU: a likelihood broker.
+
+The reference's solvers call the likelihood one theta at a time -- PolyChord runs one MPI rank per core, each calling
+`lnlhood_pc(theta)` serially (cli.py:37-41, 110; hires_fitter.py:250-262).  With one device context per rank every call
+is its own kernel launch, and launches of DIFFERENT processes do not overlap beyond a few: measured on one MI355X, four
+ranks reach 1.0e5 logL/s, six 1.2e5, and more ranks add nothing (profiles/r04_dropin.json) -- while ONE launch evaluates
+a whole batch of live points at the cost of one.
+
+The broker puts that to use without changing the solver: ONE process owns the device context and serves the ranks
+through a block of POSIX shared memory.  A rank writes its theta into its slot and bumps the slot's request counter; the
+server collects every slot with an open request, evaluates them as ONE batch (`mcalf_loglike_batch`: one launch, the
+one-launch variant of small calls), writes the values back and acknowledges.  A live point's value does not depend on
+the batch it arrives in (tests/test_gpu_timed_path.py), so every rank gets the bits it would get from its own context.
+
+    server (once per node / GPU):   with LikelihoodBroker(fit, "mcalf0", slots=64) as b: b.serve()
+    rank r (no GPU context at all): cl = BrokerClient("mcalf0", slot=r); logL, derived = cl.lnlhood_pc(theta)
+
+The client mirrors the solver-facing callables of `als_fitter` (lnlhood_pc / _dy / _mn / lnlhood_worker, _scale_cube_pc
+/ _mn) with the same return conventions.  Shared-memory ordering: plain stores and loads of CPython on x86-64 (total
+store order): theta before the request counter, logL before the acknowledgement.
+"""
+from __future__ import annotations
+
+import time
+from multiprocessing import shared_memory
+
+import numpy as np
+
+_MAGIC = 0x4D43414C46425231          # "MCALFBR1"
+_HDR = 8                             # uint64 words: magic, ndim, slots, startind, stop, served batches, served thetas, reserved
+
+
+def _layout(ndim: int, slots: int):
+    """Byte offsets of the arrays inside the block: header, request / acknowledge counters (one cache line per slot, so
+    that ranks do not share lines), bounds, results, parameter rows."""
+    off = {"hdr": 0}
+    pos = _HDR * 8
+    for name, n in (("req", slots * 8), ("ack", slots * 8), ("lo", ndim), ("hi", ndim), ("logl", slots * 8), ("theta", slots * ndim)):
+        pos = (pos + 63) & ~63
+        off[name] = pos
+        pos += n * 8
+    return off, pos
+
+
+class _Views:
+    def __init__(self, buf, ndim, slots):
+        off, _ = _layout(ndim, slots)
+        self.hdr = np.ndarray((_HDR,), dtype=np.uint64, buffer=buf, offset=off["hdr"])
+        self.req = np.ndarray((slots, 8), dtype=np.uint64, buffer=buf, offset=off["req"])[:, 0]
+        self.ack = np.ndarray((slots, 8), dtype=np.uint64, buffer=buf, offset=off["ack"])[:, 0]
+        self.lo = np.ndarray((ndim,), dtype=np.float64, buffer=buf, offset=off["lo"])
+        self.hi = np.ndarray((ndim,), dtype=np.float64, buffer=buf, offset=off["hi"])
+        self.logl = np.ndarray((slots, 8), dtype=np.float64, buffer=buf, offset=off["logl"])[:, 0]
+        self.theta = np.ndarray((slots, ndim), dtype=np.float64, buffer=buf, offset=off["theta"])
+
+
+class LikelihoodBroker:
+    """The serving side.  `fit` is anything with `ndim`, `startind`, `bounds` (as `als_fitter` holds them) and
+    `loglike_batch(P) -> logL`; the device context lives here and nowhere else."""
+
+    def __init__(self, fit, name: str, slots: int = 64):
+        self.fit, self.name, self.slots = fit, name, int(slots)
+        self.ndim = int(fit.ndim)
+        _, size = _layout(self.ndim, self.slots)
+        self.shm = shared_memory.SharedMemory(name=name, create=True, size=size)
+        self.shm.buf[:size] = bytes(size)
+        self.v = _Views(self.shm.buf, self.ndim, self.slots)
+        # min / max of every bounds entry, as _scale_cube_pc takes them (hires_fitter.py:205-206)
+        self.v.lo[:] = [np.min(b) for b in fit.bounds]
+        self.v.hi[:] = [np.max(b) for b in fit.bounds]
+        self.v.hdr[1], self.v.hdr[2], self.v.hdr[3] = self.ndim, self.slots, int(fit.startind)
+        self.v.hdr[0] = _MAGIC                                  # last: a client that sees the magic sees a complete header
+        self._batch = np.empty((self.slots, self.ndim))
+
+    def poll(self) -> int:
+        """Serve every request that is open right now as ONE batch; the number of thetas served."""
+        v = self.v
+        req = v.req.copy()                                      # (a request that arrives after this copy waits one round)
+        open_ = np.nonzero(req != v.ack)[0]
+        n = open_.size
+        if n == 0:
+            return 0
+        batch = self._batch[:n]
+        np.take(v.theta, open_, axis=0, out=batch)
+        out = self.fit.loglike_batch(batch)
+        v.logl[open_] = out
+        v.ack[open_] = req[open_]                               # acknowledge AFTER the values are in place
+        v.hdr[5] += 1
+        v.hdr[6] += n
+        return n
+
+    def serve(self, idle_sleep_after: float = 0.05, stop_when=None) -> None:
+        """Serve until a client (or `stop()`) raises the stop flag, or `stop_when()` says so.  Spins while requests keep
+        coming; after `idle_sleep_after` seconds without one it yields the core between polls."""
+        last = time.perf_counter()
+        while not self.v.hdr[4]:
+            if self.poll():
+                last = time.perf_counter()
+            elif time.perf_counter() - last > idle_sleep_after:
+                if stop_when is not None and stop_when():
+                    break
+                time.sleep(0.0002)
+
+    @property
+    def stats(self):
+        return {"batches": int(self.v.hdr[5]), "thetas": int(self.v.hdr[6])}
+
+    def stop(self):
+        self.v.hdr[4] = 1
+
+    def close(self):
+        self.v = None
+        try:
+            self.shm.close()
+            self.shm.unlink()
+        except (FileNotFoundError, BufferError):
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class BrokerClient:
+    """A solver rank's side: the likelihood callables of `als_fitter`, served by the broker `name` through slot `slot`
+    (one slot per rank; MPI rank numbers do).  Holds no device context."""
+
+    def __init__(self, name: str, slot: int, timeout: float = 60.0):
+        t0 = time.time()
+        while True:
+            try:
+                self.shm = shared_memory.SharedMemory(name=name)
+                hdr = np.ndarray((_HDR,), dtype=np.uint64, buffer=self.shm.buf)
+                if hdr[0] == _MAGIC:
+                    break
+                self.shm.close()
+            except FileNotFoundError:
+                pass
+            if time.time() - t0 > timeout:
+                raise RuntimeError(f"no likelihood broker named {name!r}")
+            time.sleep(0.01)
+        self.ndim, self.slots, self.startind = int(hdr[1]), int(hdr[2]), int(hdr[3])
+        if not (0 <= slot < self.slots):
+            raise ValueError(f"slot {slot} outside the broker's {self.slots} slots")
+        self.slot = int(slot)
+        self.v = _Views(self.shm.buf, self.ndim, self.slots)
+        self._row = self.v.theta[self.slot]
+        self.bounds = np.stack([self.v.lo, self.v.hi], axis=1).copy()
+        self._ptp = self.bounds[:, 1] - self.bounds[:, 0]
+
+    # -- the likelihood (hires_fitter.py:250-328) ---------------------------------------------------------------
+    def lnlhood_worker(self, p):
+        int(p[self.startind])                              # raises where the reference's int() does (:428)
+        v, s = self.v, self.slot
+        self._row[:] = p                                    # (raises for a wrong length)
+        seq = v.req[s] + np.uint64(1)
+        v.req[s] = seq                                      # theta first, then the request
+        ack = v.ack
+        while ack[s] != seq:
+            if v.hdr[4]:
+                raise RuntimeError("the likelihood broker has stopped")
+        return float(v.logl[s])
+
+    def lnlhood_pc(self, p):
+        return self.lnlhood_worker(p), []
+
+    def lnlhood_dy(self, p):
+        return self.lnlhood_worker(p)
+
+    def lnlhood_mn(self, p, ndim, nparam):
+        return self.lnlhood_worker(np.array([p[x] for x in range(self.ndim)]))
+
+    # -- the prior transforms (hires_fitter.py:202-216) ---------------------------------------------------------
+    def _scale_cube_pc(self, cube):
+        theta = np.array(cube, dtype=float, copy=True)     # separately rounded multiply and add, as numpy evaluates :206
+        theta *= self._ptp
+        theta += self.bounds[:, 0]
+        theta[self.startind] = int(theta[self.startind])   # :207-208
+        return theta
+
+    def _scale_cube_mn(self, cube, ndim, nparam):
+        for k in range(ndim):                               # :211-216, in place (possibly a C double pointer)
+            cube[k] = cube[k] * self._ptp[k] + self.bounds[k, 0]
+        return cube
+
+    def stop_broker(self):
+        self.v.hdr[4] = 1
+
+    def close(self):
+        self.v = self._row = None
+        try:
+            self.shm.close()
+        except BufferError:
+            pass

@@ -1,0 +1,84 @@
+"""CPU: the likelihood broker's protocol (mc-alf_amd/broker.py) with a stand-in evaluator -- several client PROCESSES,
+one server; every client gets the value of ITS theta, requests are served in batches, the callables keep the
+reference's return conventions, a stopped broker does not leave a client spinning."""
+import multiprocessing as mp
+import os
+import time
+
+import numpy as np
+import pytest
+
+from mcalf_amd import broker
+
+
+class FakeFit:
+    """Stands in for als_fitter: ndim 5, ncomp slot 1, a likelihood that is a plain function of the row."""
+    ndim, startind = 5, 1
+    bounds = [[8.0, 9.0], [1, 3], [12.0, 14.5], [2.99, 3.01], [10.0, 40.0]]
+
+    def __init__(self):
+        self.batches = []
+
+    def loglike_batch(self, P):
+        self.batches.append(len(P))
+        time.sleep(0.002)                                   # (a launch takes a while: requests pile up meanwhile)
+        return -0.5 * (P ** 2).sum(axis=1) + P[:, 0]
+
+
+def _client(name, slot, n, q):
+    cl = broker.BrokerClient(name, slot)
+    rng = np.random.default_rng(100 + slot)
+    ok = True
+    for _ in range(n):
+        p = rng.random(5) * 10 + 1
+        want = -0.5 * (p ** 2).sum() + p[0]
+        got, derived = cl.lnlhood_pc(p)
+        ok = ok and got == want and derived == []
+        ok = ok and cl.lnlhood_dy(p) == want and cl.lnlhood_mn(list(p), 5, 5) == want
+    cube = rng.random(5)
+    th = cl._scale_cube_pc(cube)
+    q.put((slot, ok, th.tolist(), cube.tolist()))
+    cl.close()
+
+
+def test_broker_serves_many_client_processes_in_batches():
+    name = f"mcalf_test_{os.getpid()}"
+    fit = FakeFit()
+    with broker.LikelihoodBroker(fit, name, slots=8) as b:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_client, args=(name, s, 40, q)) for s in range(6)]
+        for p in procs:
+            p.start()
+        t0 = time.time()
+        done = []
+        while len(done) < 6 and time.time() - t0 < 120:
+            b.poll()
+            while not q.empty():
+                done.append(q.get())
+        for p in procs:
+            p.join(timeout=30)
+        assert len(done) == 6 and all(ok for _, ok, _, _ in done)
+        assert b.stats["thetas"] == 6 * 40 * 3 and b.stats["batches"] < b.stats["thetas"]      # requests were batched
+        assert max(fit.batches) > 1
+        lo = np.array([min(x) for x in FakeFit.bounds]); hi = np.array([max(x) for x in FakeFit.bounds])
+        for _, _, th, cube in done:                          # the prior transform of hires_fitter.py:202-209, client side
+            want = np.array(cube) * (hi - lo) + lo
+            want[1] = int(want[1])
+            assert np.array_equal(np.array(th), want)
+
+
+def test_broker_client_errors():
+    name = f"mcalf_test_err_{os.getpid()}"
+    with pytest.raises(RuntimeError, match="no likelihood broker"):
+        broker.BrokerClient(name + "_absent", 0, timeout=0.05)
+    with broker.LikelihoodBroker(FakeFit(), name, slots=2) as b:
+        with pytest.raises(ValueError):
+            broker.BrokerClient(name, 2)
+        cl = broker.BrokerClient(name, 1)
+        with pytest.raises(ValueError):
+            cl.lnlhood_pc(np.array([1.0, float("nan"), 1, 1, 1]))        # int(nan), as the reference's :428
+        b.stop()
+        with pytest.raises(RuntimeError, match="stopped"):
+            cl.lnlhood_pc(np.ones(5))
+        cl.close()

@@ -6,8 +6,9 @@ aggregate logL/s for every R, with a parity check (oracle) and a cross-process b
 
     python tools/dropin_ranks.py [--config B] [--ranks 1,2,4,6,6x2,6x4] [--calls 2000] [--out profiles/r04_dropin.json]
 
-The parent never touches the GPU (a GPU box admits at most 6 processes on its card at once).  `PxT` = P processes with T
-solver threads each, every thread with its OWN context (ctypes releases the GIL for the duration of the library call):
+The parent never touches the GPU (a GPU box admits at most 6 processes on its card at once).  `bR` = R solver ranks WITHOUT device
+contexts behind one likelihood broker (mc-alf_amd/broker.py: one process owns the GPU and evaluates the ranks' thetas in
+batches); `PxT` = P processes with T solver threads each, every thread with its OWN context (ctypes releases the GIL for the duration of the library call):
 the way to put more than six contexts on the card of a box -- the GPU sees P x T independent streams of one-theta
 calls, the host side of a process serialises its threads' few microseconds of Python per call."""
 import argparse
@@ -112,6 +113,96 @@ def worker_threads(cfg, rank, nranks, calls, work, nthreads):
         json.dump(res, fh)
 
 
+def broker_server(cfg, name, slots, work):
+    """The one process with a device context: serves the clients' thetas in batches (mc-alf_amd/broker.py)."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import mcalf_amd
+    from mcalf_amd import broker, workloads
+    from cases import oracle_synth
+    kw, _, _ = workloads.config(cfg, oracle_synth)
+    fit = mcalf_amd.als_fitter(None, **kw)
+    with broker.LikelihoodBroker(fit, name, slots=slots) as b:
+        open(os.path.join(work, "server_ready"), "w").close()
+        b.serve(stop_when=lambda: os.path.exists(os.path.join(work, "stop")))
+        with open(os.path.join(work, "server.json"), "w") as fh:
+            json.dump(b.stats, fh)
+    fit.close()
+
+
+def broker_client(cfg, rank, nranks, calls, work, name):
+    """A solver rank without a device context: one theta per call through the broker."""
+    import numpy as np
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    from mcalf_amd import broker, workloads
+    from cases import oracle_synth, problem_from_kwargs
+    from oracle import numpy_oracle as orc
+    kw, _, seed = workloads.config(cfg, oracle_synth)
+    common = workloads.draw_P(kw, 32, np.random.default_rng(seed + 1000), damped=2 if cfg == "E" else 0)
+    own = workloads.draw_P(kw, calls, np.random.default_rng(seed + 2000 + rank), damped=2 if cfg == "E" else 0)
+    cl = broker.BrokerClient(name, rank)
+    for p in own[:50]:
+        cl.lnlhood_pc(p)
+    open(os.path.join(work, f"ready{rank}"), "w").close()
+    t0 = time.time()
+    while not os.path.exists(os.path.join(work, "go")):
+        assert time.time() - t0 < 120
+        time.sleep(0.0005)
+    lat = np.empty(calls)
+    tb = time.perf_counter()
+    for i, p in enumerate(own):
+        t1 = time.perf_counter()
+        cl.lnlhood_pc(p)
+        lat[i] = time.perf_counter() - t1
+    wall = time.perf_counter() - tb
+    shared = [cl.lnlhood_pc(p)[0] for p in common]
+    want = np.array([orc.lnlhood_worker(problem_from_kwargs(kw), p) for p in common[:8]]) if rank == 0 else np.array(shared[:8])
+    res = {"rank": rank, "calls": calls, "wall_s": wall, "us_mean": float(lat.mean() * 1e6), "us_median": float(np.median(lat) * 1e6),
+           "us_p99": float(np.percentile(lat, 99) * 1e6), "shared_logL": shared,
+           "max_abs_dlogL_vs_oracle": float(np.abs(np.array(shared[:8]) - want).max())}
+    cl.close()
+    with open(os.path.join(work, f"res{rank}.json"), "w") as fh:
+        json.dump(res, fh)
+
+
+def run_broker(cfg, nranks, calls):
+    work = tempfile.mkdtemp(prefix="mcalf_broker_")
+    name = "mcalf_dropin_%d" % os.getpid()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    me = os.path.abspath(__file__)
+    server = subprocess.Popen([sys.executable, me, "--broker-server", cfg, name, str(max(nranks, 1)), work], env=env)
+    t0 = time.time()
+    while not os.path.exists(os.path.join(work, "server_ready")):
+        if time.time() - t0 > 300 or server.poll() is not None:
+            raise SystemExit("the broker did not come up")
+        time.sleep(0.01)
+    procs = [subprocess.Popen([sys.executable, me, "--broker-client", cfg, str(r), str(nranks), str(calls), work, name], env=env)
+             for r in range(nranks)]
+    while not all(os.path.exists(os.path.join(work, f"ready{r}")) for r in range(nranks)):
+        if time.time() - t0 > 300 or any(p.poll() not in (None, 0) for p in procs):
+            for p in procs + [server]:
+                p.kill()
+            raise SystemExit("a client did not come up")
+        time.sleep(0.01)
+    open(os.path.join(work, "go"), "w").close()
+    for p in procs:
+        if p.wait(timeout=600) != 0:
+            server.kill()
+            raise SystemExit("a client failed")
+    open(os.path.join(work, "stop"), "w").close()
+    server.wait(timeout=60)
+    res = [json.load(open(os.path.join(work, f"res{r}.json"))) for r in range(nranks)]
+    st = json.load(open(os.path.join(work, "server.json")))
+    same = all(r["shared_logL"] == res[0]["shared_logL"] for r in res)
+    return {"ranks": nranks, "processes": nranks, "threads_per_process": 1, "broker": True, "calls_per_rank": calls,
+            "thetas_per_launch": st["thetas"] / max(st["batches"], 1),
+            "aggregate_logL_per_s": sum(r["calls"] / r["wall_s"] for r in res),
+            "us_per_call_mean": sum(r["us_mean"] for r in res) / nranks,
+            "us_per_call_median": sorted(r["us_median"] for r in res)[nranks // 2],
+            "us_per_call_p99_max": max(r["us_p99"] for r in res),
+            "bit_equal_across_ranks": same, "shared_logL_rank0": res[0]["shared_logL"],
+            "max_abs_dlogL_vs_oracle": max(r["max_abs_dlogL_vs_oracle"] for r in res)}
+
+
 def run(cfg, nranks, calls, nthreads=1):
     work = tempfile.mkdtemp(prefix="mcalf_dropin_")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -140,6 +231,12 @@ def run(cfg, nranks, calls, nthreads=1):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--broker-server":
+        broker_server(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5])
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--broker-client":
+        broker_client(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], sys.argv[7])
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--worker":
         nthr = int(sys.argv[7]) if len(sys.argv) > 7 else 1
         if nthr > 1:
@@ -155,6 +252,9 @@ def main():
     args = ap.parse_args()
     rows = []
     for spec in args.ranks.split(","):
+        if spec.startswith("b"):                            # bR: R ranks WITHOUT device contexts behind one likelihood broker
+            rows.append(run_broker(args.config, int(spec[1:]), args.calls))
+            continue
         pr, _, thr = spec.partition("x")
         rows.append(run(args.config, int(pr), args.calls, int(thr) if thr else 1))
     ref = rows[0]["shared_logL_rank0"]
@@ -163,6 +263,8 @@ def main():
            "bit_equal_across_runs": all(r["shared_logL_rank0"] == ref for r in rows)}
     for r in rows:
         del r["shared_logL_rank0"]
+        if r.get("broker"):
+            print("R = %d ranks behind ONE broker (%.1f thetas per launch):" % (r["ranks"], r["thetas_per_launch"]), end=" ")
         print("R = %d (%d processes x %d threads): %.1f us per call (median %.1f, worst p99 %.1f), %.0f logL/s aggregate, bit-equal %s, |dlogL| vs oracle %.1e"
               % (r["ranks"], r["processes"], r["threads_per_process"], r["us_per_call_mean"], r["us_per_call_median"], r["us_per_call_p99_max"], r["aggregate_logL_per_s"],
                  r["bit_equal_across_ranks"], r["max_abs_dlogL_vs_oracle"]))
