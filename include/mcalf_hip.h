@@ -138,8 +138,9 @@ int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batch, int32_t 
 
 /* Row blocks a batch is issued in (0 = automatic [default], n <= 8 = exactly n).  Automatic means ONE block
  * for the *_device entries (the persistent fused kernel leaves no launch tail worth filling; measured) and, for
- * the host-pointer entries with large batches, ONE streaming launch (MCALF_PATH_HOST_STREAM; an explicit block count,
- * MCALF_STREAM=0 or a launch below the persistent-grid threshold selects the row-block pipeline instead: a small first
+ * the host-pointer entries with large batches, ONE streaming launch (MCALF_PATH_HOST_STREAM: spectra that fit one pixel
+ * tile; MCALF_STREAM=2 streams tiled ones too; an explicit block count, MCALF_STREAM=0, a tiled spectrum or a launch
+ * below the persistent-grid threshold selects the row-block pipeline instead: a small first
  * block followed by larger ones, 1:1:2:4 of the rows for pageable input, 1:7 for page-locked input, so that block k+1's
  * H2D copy and per-sample set-up run under block k's kernel).  With more than one block in a *_device call the
  * blocks after the first run on context-owned streams between a fork event recorded on the caller's stream and

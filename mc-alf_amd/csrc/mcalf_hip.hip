@@ -1494,7 +1494,9 @@ struct mcalf_ctx {
     volatile unsigned int* h_ctl = nullptr;
     unsigned int* d_ctl = nullptr;          // the same words as the device sees them
     unsigned int stream_gen = 0;
-    int stream_on = 1;                      // MCALF_STREAM=0: the row-block pipeline of round 2 instead
+    int stream_on = 1;                      // MCALF_STREAM: 0 = the row-block pipeline of round 2 instead; 1 = automatic (spectra that
+                                            // fit one tile: measured, config E's five tiles per live point run 1.3 % faster through
+                                            // the pipeline); 2 = always
     int stream_wgs = 16;                    // MCALF_STREAM_WGS: workgroups dedicated to the set-up while rows are outstanding
     int stream_eager = 0;                   // MCALF_STREAM_EAGER: blocks of 8 rows per XCD any workgroup may set up (0: what the first items need)
     int stream_chunk = 32;                  // MCALF_STREAM_CHUNK: rows such a workgroup claims (and copies to HBM) at a time
@@ -1877,7 +1879,7 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
             if (n > 0) ctx->host_plan_n = n;
         }
         if (const char* fp = std::getenv("MCALF_TEST_FAIL_PREFLIGHT")) ctx->fail_preflight = std::atoi(fp) != 0;
-        if (const char* e = std::getenv("MCALF_STREAM")) ctx->stream_on = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MCALF_STREAM")) ctx->stream_on = std::min(std::max(std::atoi(e), 0), 2);
         if (const char* e = std::getenv("MCALF_STREAM_WGS")) ctx->stream_wgs = std::min(std::max(std::atoi(e), 1), ctx->num_cu);
         if (const char* e = std::getenv("MCALF_STREAM_POLL")) ctx->stream_poll = std::atoi(e) != 0;
         if (const char* e = std::getenv("MCALF_STREAM_EAGER")) ctx->stream_eager = std::max(std::atoi(e), 0);
@@ -2424,6 +2426,7 @@ static int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t ba
     double tm[7] = {};
     if (trace) tm[0] = now_us();
     if (!ctx->stream_on || ctx->chunks_req > 0 || ctx->host_plan_n > 0 || ctx->profiling || !stream_qualifies(ctx, batch)) return MCALF_OK;
+    if (ctx->stream_on == 1 && ctx->ntiles > 1) return MCALF_OK;
     const bool pin_in = is_pinned_host(P), pin_out = is_pinned_host(out_scalar);
     const double* dP_view = nullptr;
     if (pin_in && hipHostGetDevicePointer((void**)&dP_view, const_cast<double*>(P), 0) != hipSuccess) {

@@ -3,13 +3,28 @@ context on the one GPU, each calling lnlhood_pc one theta at a time -- gives eve
 process gets, within the parity bar of the oracle."""
 import os
 import sys
+import time
 
+import numpy as np
 import pytest
+
+import mcalf_amd
+from mcalf_amd import workloads
+from cases import oracle_synth
 
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _broker_rank(name, rank, rows, q):
+    """A solver rank of the broker test: no device context, one theta per call."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    from mcalf_amd import broker
+    cl = broker.BrokerClient(name, rank)
+    q.put((rank, [cl.lnlhood_pc(p)[0] for p in rows]))
+    cl.close()
 
 
 def test_two_concurrent_processes_get_the_bits_of_one():
@@ -20,3 +35,35 @@ def test_two_concurrent_processes_get_the_bits_of_one():
     assert one["shared_logL_rank0"] == two["shared_logL_rank0"]           # 32 thetas, bit for bit
     assert max(one["max_abs_dlogL_vs_oracle"], two["max_abs_dlogL_vs_oracle"]) < 1e-4
     assert two["aggregate_logL_per_s"] > 0
+
+
+def test_ranks_behind_the_likelihood_broker_get_the_bits_of_their_own_context():
+    """mc-alf_amd/broker.py: ONE process owns the device context and serves solver ranks (processes WITHOUT a GPU context)
+    through shared memory, evaluating their thetas in batches.  Every rank's logL equals what `lnlhood_pc` of an own
+    context gives, to the bit (a live point's value does not depend on the batch it arrives in)."""
+    import multiprocessing as mp
+    from mcalf_amd import broker
+    kw, _, seed = workloads.config("B", oracle_synth)
+    P = workloads.draw_P(kw, 24, np.random.default_rng(seed + 5))
+    name = f"mcalf_gputest_{os.getpid()}"
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        want = [fit.lnlhood_pc(p)[0] for p in P]
+        with broker.LikelihoodBroker(fit, name, slots=4) as b:
+            ctx = mp.get_context("spawn")
+            q = ctx.Queue()
+            procs = [ctx.Process(target=_broker_rank, args=(name, r, P[r::3], q)) for r in range(3)]
+            for p in procs:
+                p.start()
+            got = {}
+            t0 = time.time()
+            while len(got) < 3 and time.time() - t0 < 240:
+                b.poll()
+                while not q.empty():
+                    r, vals = q.get()
+                    got[r] = vals
+            for p in procs:
+                p.join(timeout=30)
+            assert len(got) == 3
+            for r in range(3):
+                assert got[r] == want[r::3]
+            assert b.stats["thetas"] == 24
