@@ -1,8 +1,12 @@
 """GPU: the N > 1 branch of the in-library gather (mcalf_loglike_gatherv_device: grouped receives on the root, send
 on the others, ragged counts, the exchange stream with and without overlap, the NaN-block error path) driven by TWO
 processes on the one GPU of a box.  RCCL itself refuses two ranks on one device, so the transport is the test-only
-stand-in tests/stubs/fake_rccl.cpp behind MCALF_RCCL_LIB: this checks the library's control flow, offsets and error
-handling, NOT RCCL -- RCCL with more than one rank runs only on the driver's multi-GPU node."""
+stand-in tests/stubs/fake_rccl.cpp behind MCALF_RCCL_LIB -- asynchronous and stream-ordered like the real library, with
+every receive landing 2 ms AFTER its message is there (FAKE_RCCL_DELAY_US), so that the gathered vectors are right only
+if the library's stream / event chain around the exchange is: every step evaluates a different parameter matrix, and a
+negative control (one local buffer for all overlapped steps, against the documented contract) must come out wrong.
+This checks the library's control flow, offsets, ordering and error handling, NOT RCCL -- RCCL with more than one rank
+runs only on the driver's multi-GPU node."""
 import json
 import os
 import shutil
@@ -31,8 +35,9 @@ def fake_rccl(tmp_path_factory):
 
 
 def _run(mode, work, fake):
-    env = dict(os.environ, MCALF_RCCL_LIB=fake, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MCALF_RCCL_LIB=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", FAKE_RCCL_DELAY_US="2000")
     env.pop("MCALF_TEST_FAIL_PREFLIGHT", None)
+    env.pop("FAKE_RCCL_SYNC", None)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gather_worker.py"), str(r), "2", work, mode],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = []
@@ -48,34 +53,48 @@ def _run(mode, work, fake):
     return [json.load(open(os.path.join(work, f"rank{r}.json"))) for r in range(2)]
 
 
-def _expected():
+@pytest.fixture(scope="module")
+def expected():
+    """logL of the eight parameter matrices the worker's steps evaluate, from one process."""
     kw, _, seed = workloads.config("C", oracle_synth)
-    P = workloads.draw_P(kw, 1001, np.random.default_rng(seed + 99))
     with mcalf_amd.als_fitter(None, **kw) as fit:
-        return fit.loglike_batch(P)
+        return [fit.loglike_batch(workloads.draw_P(kw, 1001, np.random.default_rng(seed + 99 + v))) for v in range(8)]
 
 
-def test_two_ranks_ragged_gather_equals_the_single_process_result(tmp_path, fake_rccl):
-    want = _expected()
+def _vectors(r0):
+    """step variant -> gathered vector, for the steps whose gather the worker reads back."""
+    return {0: r0["plain"][0], 1: r0["plain"][1], 2: r0["overlap_2_3"][0], 3: r0["overlap_2_3"][1],
+            6: r0["overlap_6_7"][0], 7: r0["overlap_6_7"][1]}
+
+
+def test_two_ranks_ragged_gather_equals_the_single_process_result(tmp_path, fake_rccl, expected):
     r0, r1 = _run("ok", str(tmp_path), fake_rccl)
-    assert r0["codes"] == [0] * 6 and r1["codes"] == [0] * 6
+    assert r0["codes"] == [0] * 8 and r1["codes"] == [0] * 8
     assert r0["comm"] == [2, 0] and r1["comm"] == [2, 1]
-    assert np.array_equal(np.array(r0["plain"]), want)              # 501 + 500 rows, bit for bit
-    for k in range(2):                                               # both buffer pairs of the overlapped steps
-        assert np.array_equal(np.array(r0["overlap"][k]), want)
+    assert not np.array_equal(expected[6], expected[7])
+    for v, got in _vectors(r0).items():                              # 501 + 500 rows, bit for bit, every step its own values
+        assert np.array_equal(np.array(got), expected[v]), v
 
 
-def test_a_rank_that_fails_locally_sends_nans_and_nobody_hangs(tmp_path, fake_rccl):
-    want = _expected()
+def test_negative_control_one_local_buffer_in_overlap_mode_shows(tmp_path, fake_rccl, expected):
+    """Against the contract of overlap mode the worker hands every step the SAME local buffer: step 6's block leaves rank 1
+    only after step 7's kernels have rewritten it.  The stand-in transport must be asynchronous enough to show that --
+    otherwise the test above could not tell a missing event wait from a present one."""
+    r0, r1 = _run("racy", str(tmp_path), fake_rccl)
+    assert r0["codes"] == [0] * 8 and r1["codes"] == [0] * 8
+    got = _vectors(r0)
+    assert np.array_equal(np.array(got[7]), expected[7])             # the last step is right in any case ...
+    assert not np.array_equal(np.array(got[6])[501:], expected[6][501:])   # ... the one before it is not
+
+
+def test_a_rank_that_fails_locally_sends_nans_and_nobody_hangs(tmp_path, fake_rccl, expected):
     r0, r1 = _run("fail", str(tmp_path), fake_rccl)
-    assert r0["codes"] == [0] * 6                                    # the root is fine ...
-    assert r1["codes"] == [_lib.MCALF_ERR_NOMEM] * 6                 # ... rank 1 reports its failure every time
+    assert r0["codes"] == [0] * 8                                    # the root is fine ...
+    assert r1["codes"] == [_lib.MCALF_ERR_NOMEM] * 8                 # ... rank 1 reports its failure every time
     assert "NaN" in r1["err"] and "MCALF_TEST_FAIL_PREFLIGHT" in r1["err"]
-    got = np.array(r0["plain"])
-    assert np.array_equal(got[:501], want[:501]) and np.isnan(got[501:]).all()
-    for k in range(2):
-        g = np.array(r0["overlap"][k])
-        assert np.array_equal(g[:501], want[:501]) and np.isnan(g[501:]).all()
+    for v, got in _vectors(r0).items():
+        g = np.array(got)
+        assert np.array_equal(g[:501], expected[v][:501]) and np.isnan(g[501:]).all(), v
 
 
 def test_argument_errors_return_a_code_and_the_context_destroys_cleanly():
