@@ -220,6 +220,9 @@ def main():
                          "on the launch stream); inlib_overlap = the same with the exchange on the context's side stream")
     ap.add_argument("--leg-timeout", type=float, default=30.0,
                     help="N>1: seconds a library-gather leg may take before the watchdog prints what has been measured and exits")
+    ap.add_argument("--init-timeout", type=float, default=120.0,
+                    help="N>1: seconds the library's communicator may take to come up (ncclCommInitRank over all ranks; its "
+                         "own allowance, so that a slow first initialisation is not mistaken for a hung exchange)")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer (PCIe-inclusive) passes")
     ap.add_argument("--no-strong-ref", action="store_true", help="N=1: skip the config-D-on-one-GPU reference")
     ap.add_argument("--no-model-leg", action="store_true", help="N=1: skip the model-output (reconstruct_spec) passes")
@@ -406,7 +409,7 @@ def main():
     # tests' stand-in transport (MCALF_RCCL_LIB)
     can_inlib = use_dist and (not rehearsal or bool(os.environ.get("MCALF_RCCL_LIB")))
 
-    def emit_partial_and_exit(name):
+    def emit_partial_and_exit(name, what=None):
         """Watchdog of a library-gather leg: print what has been measured, exit non-zero (a fresh exit, never a re-exec)."""
         leg_notes[name] = "timed_out"
         if rank == 0:
@@ -418,7 +421,7 @@ def main():
                     "ms_per_step": (legs[best]["elapsed"] / args.steps * 1e3) if best else None,
                     "gather_reported": best, "gathers": {**done, name: "timed_out"},
                     "config": {"workload": WORKLOAD_LABEL[config], "batch_per_gpu": batch, "global_batch": batch * world},
-                    "error": f"gather leg {name!r} did not finish within {args.leg_timeout:.0f} s"}
+                    "error": what or f"gather leg {name!r} did not finish within {args.leg_timeout:.0f} s"}
             print(json.dumps(line), flush=True)
         os._exit(3)
 
@@ -428,10 +431,15 @@ def main():
             continue
         watchdog = None
         if name != "torch":
+            init_dog = threading.Timer(args.init_timeout, emit_partial_and_exit, args=(
+                name, f"the communicator of gather leg {name!r} did not come up within {args.init_timeout:.0f} s"))
+            init_dog.daemon = True
+            init_dog.start()
+            inlib_box[0] = mdist.InLibGather(fit, batch * world, dev, depth=2 if name == "inlib_overlap" else 1)
+            init_dog.cancel()
             watchdog = threading.Timer(args.leg_timeout, emit_partial_and_exit, args=(name,))
             watchdog.daemon = True
             watchdog.start()
-            inlib_box[0] = mdist.InLibGather(fit, batch * world, dev, depth=2 if name == "inlib_overlap" else 1)
         legs[name] = run_leg()
         if watchdog is not None:
             watchdog.cancel()
