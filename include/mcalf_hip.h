@@ -40,8 +40,9 @@
 extern "C" {
 #endif
 
-#define MCALF_ABI_VERSION 3   /* 2: mcalf_last_launch, gatherv / overlap / join, version string carries the source hash
-                                 3: MCALF_PATH_HOST_STREAM, mcalf_launch_info_t grows by stream_setup_wgs / stream_polled */
+#define MCALF_ABI_VERSION 4   /* 2: mcalf_last_launch, gatherv / overlap / join, version string carries the source hash
+                                 3: MCALF_PATH_HOST_STREAM, mcalf_launch_info_t grows by stream_setup_wgs / stream_polled
+                                 4: mcalf_broker_serve */
 
 enum {
     MCALF_OK = 0,
@@ -135,6 +136,29 @@ int mcalf_chi2_batch(mcalf_ctx* ctx, const double* P, int64_t batch, double* chi
  * component (reconstruct_onecomp); 1: the filler line (reconstruct_onecomp_fill); 2 + k: line k
  * alone (the per-line model calc_w integrates, hires_fitter.py:483). */
 int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batch, int32_t which, double* flux);
+
+/* Likelihood broker, serving side: MANY one-theta-at-a-time solver ranks (PolyChord runs one MPI rank per core, each calling
+ * lnlhood_pc(theta) serially: cli.py:37-41, 110; hires_fitter.py:250-262) served by ONE thread of ONE process that owns the
+ * device contexts.  The request block lives wherever the caller puts it (mc-alf_amd/broker.py: POSIX shared memory); rank s
+ * writes its row theta[s * theta_stride ..], then bumps req[s * counter_stride]; the server evaluates every open request of
+ * the moment as one small batch on a context that is free, writes logl[s * logl_stride] and then sets ack[..] to the
+ * request number.  With several contexts, requests that arrive while a launch is in flight leave at once on the next free
+ * context.  Returns when *stop becomes non-zero (after answering what is in flight) or after max_seconds (0: never). */
+typedef struct {
+    int32_t slots;              /* request slots, one per solver rank */
+    int32_t ndim;               /* doubles per parameter row (the contexts' ndim) */
+    volatile uint64_t* req;     /* [slots * counter_stride] */
+    volatile uint64_t* ack;     /* [slots * counter_stride] */
+    int64_t counter_stride;     /* in 64-bit words (8: one cache line per slot) */
+    const double* theta;        /* [slots * theta_stride] */
+    int64_t theta_stride;       /* in doubles, >= ndim */
+    double* logl;               /* [slots * logl_stride] */
+    int64_t logl_stride;        /* in doubles */
+    volatile uint64_t* stop;
+    uint64_t* stats;            /* optional [2]: launches and thetas served so far (incremented) */
+    double idle_sleep_after_s;  /* spin this long without a request before yielding the core between polls */
+} mcalf_broker_t;
+int mcalf_broker_serve(mcalf_ctx* const* ctxs, int32_t nctx, const mcalf_broker_t* b, double max_seconds);
 
 /* Row blocks a batch is issued in (0 = automatic [default], n <= 8 = exactly n).  Automatic means ONE block
  * for the *_device entries (the persistent fused kernel leaves no launch tail worth filling; measured) and, for

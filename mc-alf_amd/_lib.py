@@ -88,6 +88,23 @@ class mcalf_launch_info_t(C.Structure):
     ]
 
 
+class mcalf_broker_t(C.Structure):
+    _fields_ = [
+        ("slots", C.c_int32),
+        ("ndim", C.c_int32),
+        ("req", C.c_void_p),
+        ("ack", C.c_void_p),
+        ("counter_stride", C.c_int64),
+        ("theta", C.c_void_p),
+        ("theta_stride", C.c_int64),
+        ("logl", C.c_void_p),
+        ("logl_stride", C.c_int64),
+        ("stop", C.c_void_p),
+        ("stats", C.c_void_p),
+        ("idle_sleep_after_s", C.c_double),
+    ]
+
+
 # every symbol include/mcalf_hip.h declares: name -> (restype, argtypes)
 _PD = C.POINTER(C.c_double)
 _CTX = C.c_void_p
@@ -114,6 +131,7 @@ SYMBOLS = {
     "mcalf_set_prior": (C.c_int, [_CTX, _PD, _PD, C.c_int32]),
     "mcalf_loglike_cube_batch": (C.c_int, [_CTX, _PD, C.c_int64, _PD, _PD]),
     "mcalf_loglike_cube_batch_device": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mcalf_broker_serve": (C.c_int, [C.POINTER(_CTX), C.c_int32, C.POINTER(mcalf_broker_t), C.c_double]),
     "mcalf_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mcalf_comm_init": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32]),
     "mcalf_comm_info": (C.c_int, [_CTX, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

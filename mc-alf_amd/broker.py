@@ -15,12 +15,18 @@ the batch it arrives in (tests/test_gpu_timed_path.py), so every rank gets the b
     server (once per node / GPU):   with LikelihoodBroker(fit, "mcalf0", slots=64) as b: b.serve()
     rank r (no GPU context at all): cl = BrokerClient("mcalf0", slot=r); logL, derived = cl.lnlhood_pc(theta)
 
+`serve()` runs the loop inside the library when the evaluator is an `als_fitter` (`mcalf_broker_serve`: one C thread, no
+interpreter in the round), and with SEVERAL contexts of the same problem (`LikelihoodBroker([fit_a, fit_b, ...], ...)`)
+requests that arrive while a launch is in flight leave at once on the next free context instead of waiting for it to
+end.  `poll()` / `serve(native=False)` are the same protocol in Python, for any object with `loglike_batch`.
+
 The client mirrors the solver-facing callables of `als_fitter` (lnlhood_pc / _dy / _mn / lnlhood_worker, _scale_cube_pc
 / _mn) with the same return conventions.  Shared-memory ordering: plain stores and loads of CPython on x86-64 (total
 store order): theta before the request counter, logL before the acknowledgement.
 """
 from __future__ import annotations
 
+import ctypes as C
 import time
 from multiprocessing import shared_memory
 
@@ -56,9 +62,14 @@ class _Views:
 
 class LikelihoodBroker:
     """The serving side.  `fit` is anything with `ndim`, `startind`, `bounds` (as `als_fitter` holds them) and
-    `loglike_batch(P) -> logL`; the device context lives here and nowhere else."""
+    `loglike_batch(P) -> logL` -- or a sequence of such evaluators of the SAME problem, one launch in flight on each
+    (native loop only); the device contexts live here and nowhere else."""
 
     def __init__(self, fit, name: str, slots: int = 64):
+        self.fits = list(fit) if isinstance(fit, (list, tuple)) else [fit]
+        fit = self.fits[0]
+        if any(int(f.ndim) != int(fit.ndim) for f in self.fits):
+            raise ValueError("the broker's evaluators must describe the same problem")
         self.fit, self.name, self.slots = fit, name, int(slots)
         self.ndim = int(fit.ndim)
         _, size = _layout(self.ndim, self.slots)
@@ -89,9 +100,31 @@ class LikelihoodBroker:
         v.hdr[6] += n
         return n
 
-    def serve(self, idle_sleep_after: float = 0.05, stop_when=None) -> None:
+    @property
+    def native(self) -> bool:
+        """Whether every evaluator is a device context of the library (the loop can then run inside it)."""
+        return all(getattr(f, "_ctx", None) is not None and hasattr(getattr(f, "_lib", None), "mcalf_broker_serve") for f in self.fits)
+
+    def serve_native(self, idle_sleep_after: float = 0.05, max_seconds: float = 0.0) -> None:
+        """The loop inside the library (mcalf_broker_serve): returns when the stop flag is raised, or after `max_seconds`."""
+        from . import _lib
+        off, _ = _layout(self.ndim, self.slots)
+        base = C.addressof(C.c_char.from_buffer(self.shm.buf))
+        d = _lib.mcalf_broker_t(slots=self.slots, ndim=self.ndim, req=base + off["req"], ack=base + off["ack"], counter_stride=8,
+                                theta=base + off["theta"], theta_stride=self.ndim, logl=base + off["logl"], logl_stride=8,
+                                stop=base + off["hdr"] + 4 * 8, stats=base + off["hdr"] + 5 * 8, idle_sleep_after_s=idle_sleep_after)
+        ctxs = (C.c_void_p * len(self.fits))(*[f._ctx for f in self.fits])
+        rc = self.fit._lib.mcalf_broker_serve(ctxs, len(self.fits), C.byref(d), float(max_seconds))
+        _lib.check(rc, self.fit._ctx)
+
+    def serve(self, idle_sleep_after: float = 0.05, stop_when=None, native=None) -> None:
         """Serve until a client (or `stop()`) raises the stop flag, or `stop_when()` says so.  Spins while requests keep
-        coming; after `idle_sleep_after` seconds without one it yields the core between polls."""
+        coming; after `idle_sleep_after` seconds without one it yields the core between polls.  `native` (default: when
+        every evaluator is a library context and no `stop_when` is given) runs the loop inside the library."""
+        if native is None:
+            native = self.native and stop_when is None
+        if native:
+            return self.serve_native(idle_sleep_after)
         last = time.perf_counter()
         while not self.v.hdr[4]:
             if self.poll():
@@ -132,6 +165,13 @@ class BrokerClient:
         while True:
             try:
                 self.shm = shared_memory.SharedMemory(name=name)
+                # (Python < 3.13 registers an ATTACHED block with the process's resource tracker as if it had created it,
+                # and the tracker unlinks it when this rank exits -- under the other ranks' feet: the block is the server's)
+                try:
+                    from multiprocessing import resource_tracker
+                    resource_tracker.unregister(self.shm._name, "shared_memory")
+                except Exception:  # noqa: BLE001 - private API; the worst case is the warning at exit
+                    pass
                 hdr = np.ndarray((_HDR,), dtype=np.uint64, buffer=self.shm.buf)
                 if hdr[0] == _MAGIC:
                     break

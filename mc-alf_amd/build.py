@@ -58,4 +58,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    if "--hash" in sys.argv:                  # (the Makefile stamps the library with it)
+        print(source_hash())
+    else:
+        print(build(force=True, verbose=True))

@@ -2517,6 +2517,15 @@ static int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t ba
     return MCALF_OK;
 }
 
+// The page-locked, device-mapped block small calls go through: parameters in its first half, results in its second.
+static int ensure_small(mcalf_ctx* ctx) {
+    if (!ctx->h_small) {
+        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_small, 2 * kSmallDoubles * sizeof(double), hipHostMallocMapped));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->d_small, ctx->h_small, 0));
+    }
+    return MCALF_OK;
+}
+
 // Host-pointer entries: stage through the context's workspaces on its private stream.
 static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
                     double* out_scalar, double* out_model) {
@@ -2528,10 +2537,7 @@ static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
     int rc;
     if (out_scalar && !out_model && (size_t)batch * rowlen <= kSmallDoubles && (size_t)batch <= kSmallDoubles) {
         // zero-copy path: a single-theta call is dominated by the latency of its two copy commands
-        if (!ctx->h_small) {
-            HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_small, 2 * kSmallDoubles * sizeof(double), hipHostMallocMapped));
-            HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->d_small, ctx->h_small, 0));
-        }
+        if ((rc = ensure_small(ctx))) return rc;
         std::memcpy(ctx->h_small, P, (size_t)batch * rowlen * sizeof(double));
         ctx->last.path = MCALF_PATH_HOST_ZEROCOPY; ctx->last.pinned_in = ctx->last.pinned_out = 0;
         rc = launch(ctx, mode, ctx->d_small, batch, targonly, fill, ctx->d_small + kSmallDoubles, nullptr, ctx->stream);
@@ -2583,6 +2589,121 @@ extern "C" int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batc
         return set_err(ctx, MCALF_ERR_INVALID, "onecomp: `which` must be 0 (all lines), 1 (filler) or 2+k with k < %d",
                        ctx->nlines);
     return run_host(ctx, kModeOneComp, Q, batch, 5, 0, which, nullptr, flux);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Likelihood broker, serving side (many one-theta-at-a-time solver ranks on one GPU; mc-alf_amd/broker.py holds the
+// shared-memory protocol and the ranks' side).  The reference's solvers call the likelihood one theta at a time, one
+// MPI rank per core (cli.py:37-41, 110; hires_fitter.py:250-262); launches of DIFFERENT processes do not overlap
+// beyond a few, launches of ONE process on several streams do.  So one thread of one process serves every rank: it
+// collects the open requests, evaluates them as one small batch on a context that is free (the one-launch variant of
+// small calls, parameters and results in page-locked memory, nothing synchronous) and goes on polling -- requests that
+// arrive while a launch is in flight leave at once on the next free context instead of waiting for it to end.
+// A live point's value does not depend on the batch it is evaluated in, so every rank gets the bits its own context
+// would give.
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int mcalf_broker_serve(mcalf_ctx* const* ctxs, int32_t nctx, const mcalf_broker_t* b, double max_seconds) {
+    constexpr int kMaxLanes = 8;
+    if (!ctxs || nctx < 1 || nctx > kMaxLanes || !ctxs[0]) return set_err(nullptr, MCALF_ERR_INVALID, "broker: 1 .. %d contexts", kMaxLanes);
+    mcalf_ctx* c0 = ctxs[0];
+    if (!b || b->slots < 1 || b->slots > 65536 || !b->req || !b->ack || !b->theta || !b->logl || !b->stop || b->counter_stride < 1 ||
+        b->theta_stride < b->ndim || b->logl_stride < 1)
+        return set_err(c0, MCALF_ERR_INVALID, "broker: incomplete description of the request block");
+    struct Lane { mcalf_ctx* c; int n; bool busy; unsigned long polls; std::vector<int> slot; std::vector<uint64_t> seq; };
+    // Completion of a launch is read off its results: the slots are filled with a NaN no kernel produces before the
+    // launch, and the launch is over when none is left (the results land in page-locked memory; asking the runtime --
+    // hipStreamQuery in a loop -- cost more per round than the Python loop's blocking wait).  The stream is asked only
+    // now and then, so that a failed launch cannot keep the loop waiting.
+    constexpr uint64_t kPending = 0x7FF8C0DEC0DE0001ull;
+    Lane lane[kMaxLanes];
+    int rc;
+    for (int k = 0; k < nctx; ++k) {
+        mcalf_ctx* c = ctxs[k];
+        if (!c || c->ndim != b->ndim) return set_err(c0, MCALF_ERR_INVALID, "broker: context %d does not take rows of %d parameters", k, b->ndim);
+        for (int j = 0; j < k; ++j)
+            if (ctxs[j] == c) return set_err(c0, MCALF_ERR_INVALID, "broker: context %d is listed twice (a context holds one batch at a time)", k);
+        HIP_TRY(c, hipSetDevice(c->device));
+        if ((rc = ensure_small(c))) return rc;
+        lane[k].c = c; lane[k].n = 0; lane[k].busy = false; lane[k].polls = 0;
+    }
+    const int ndim = b->ndim, slots = b->slots;
+    const int cap = (int)std::min<size_t>((size_t)slots, kSmallDoubles / (size_t)ndim);    // live points per launch
+    std::vector<unsigned char> inflight((size_t)slots, 0);
+    const double t_begin = now_us();
+    double t_last = t_begin;
+    bool stopping = false;
+    auto finish = [&](Lane& L) {                          // results first, then the acknowledgement the rank is polling
+        for (int i = 0; i < L.n; ++i) b->logl[(size_t)L.slot[i] * b->logl_stride] = L.c->h_small[kSmallDoubles + i];
+        for (int i = 0; i < L.n; ++i) {
+            __atomic_store_n(const_cast<uint64_t*>(b->ack + (size_t)L.slot[i] * b->counter_stride), L.seq[i], __ATOMIC_RELEASE);
+            inflight[(size_t)L.slot[i]] = 0;
+        }
+        if (b->stats) { b->stats[0] += 1; b->stats[1] += (uint64_t)L.n; }
+        L.busy = false;
+    };
+    while (true) {
+        bool progress = false, any_busy = false;
+        int free_lane = -1;
+        for (int k = 0; k < nctx; ++k) {
+            Lane& L = lane[k];
+            if (L.busy) {
+                const uint64_t* res = reinterpret_cast<const uint64_t*>(L.c->h_small + kSmallDoubles);
+                bool done = true;
+                for (int i = L.n - 1; i >= 0 && done; --i) done = __atomic_load_n(res + i, __ATOMIC_ACQUIRE) != kPending;
+                if (done) { finish(L); progress = true; }
+                else if ((++L.polls & 0x3FFFul) == 0) {
+                    const hipError_t q = hipStreamQuery(L.c->stream);
+                    if (q == hipSuccess) {                 // (the stream has drained: every result must be there now)
+                        for (int i = 0; i < L.n; ++i)
+                            if (__atomic_load_n(res + i, __ATOMIC_ACQUIRE) == kPending)
+                                return set_err(L.c, MCALF_ERR_HIP, "broker: a launch ended without its results");
+                    } else if (q != hipErrorNotReady) {
+                        return set_err(L.c, MCALF_ERR_HIP, "broker: launch failed: %s", hipGetErrorString(q));
+                    }
+                }
+            }
+            if (L.busy) any_busy = true;
+            else if (free_lane < 0) free_lane = k;
+        }
+        if (__atomic_load_n(const_cast<uint64_t*>(b->stop), __ATOMIC_ACQUIRE) != 0) stopping = true;
+        if (stopping) {
+            if (!any_busy) return MCALF_OK;               // (what was in flight has been answered)
+            continue;
+        }
+        if (free_lane >= 0) {
+            Lane& L = lane[free_lane];
+            L.slot.clear(); L.seq.clear();
+            for (int s = 0; s < slots && (int)L.slot.size() < cap; ++s) {
+                if (inflight[(size_t)s]) continue;
+                const uint64_t r = __atomic_load_n(const_cast<uint64_t*>(b->req + (size_t)s * b->counter_stride), __ATOMIC_ACQUIRE);
+                if (r != b->ack[(size_t)s * b->counter_stride]) { L.slot.push_back(s); L.seq.push_back(r); }
+            }
+            L.n = (int)L.slot.size();
+            if (L.n > 0) {
+                for (int i = 0; i < L.n; ++i)
+                    std::memcpy(L.c->h_small + (size_t)i * ndim, b->theta + (size_t)L.slot[i] * b->theta_stride, (size_t)ndim * sizeof(double));
+                uint64_t* res = reinterpret_cast<uint64_t*>(L.c->h_small + kSmallDoubles);
+                for (int i = 0; i < L.n; ++i) __atomic_store_n(res + i, kPending, __ATOMIC_RELEASE);
+                L.polls = 0;
+                L.c->last.path = MCALF_PATH_HOST_ZEROCOPY; L.c->last.pinned_in = L.c->last.pinned_out = 0;
+                if ((rc = launch(L.c, kModeLogL, L.c->d_small, L.n, 0, 0, L.c->d_small + kSmallDoubles, nullptr, L.c->stream))) {
+                    for (int k = 0; k < nctx; ++k)
+                        if (lane[k].busy) (void)hipStreamSynchronize(lane[k].c->stream);
+                    return rc;
+                }
+                for (int i = 0; i < L.n; ++i) inflight[(size_t)L.slot[i]] = 1;
+                L.busy = true;
+                progress = true;
+            }
+        }
+        const double t = now_us();
+        if (progress) t_last = t;
+        else if (!any_busy && (t - t_last) * 1e-6 > b->idle_sleep_after_s) {
+            struct timespec ts = {0, 200000};             // nobody has asked for a while: yield the core between polls
+            nanosleep(&ts, nullptr);
+        }
+        if (max_seconds > 0 && (t - t_begin) * 1e-6 > max_seconds) stopping = true;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

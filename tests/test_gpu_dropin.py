@@ -67,3 +67,46 @@ def test_ranks_behind_the_likelihood_broker_get_the_bits_of_their_own_context():
             for r in range(3):
                 assert got[r] == want[r::3]
             assert b.stats["thetas"] == 24
+
+
+def test_the_librarys_broker_loop_over_two_contexts_gives_the_same_bits():
+    """mcalf_broker_serve: the serving loop inside the library, one C thread over TWO contexts of the same problem (requests
+    that arrive while a launch is in flight leave on the other context).  Three ranks without a device context; every logL
+    equals lnlhood_pc of an own context to the bit; the loop returns once the stop flag is raised."""
+    import multiprocessing as mp
+    import threading
+    from mcalf_amd import broker
+    kw, _, seed = workloads.config("B", oracle_synth)
+    P = workloads.draw_P(kw, 30, np.random.default_rng(seed + 6))
+    name = f"mcalf_gputest_native_{os.getpid()}"
+    with mcalf_amd.als_fitter(None, **kw) as fit, mcalf_amd.als_fitter(None, **kw) as fit2:
+        want = [fit.lnlhood_pc(p)[0] for p in P]
+        with broker.LikelihoodBroker([fit, fit2], name, slots=4) as b:
+            assert b.native
+            server = threading.Thread(target=b.serve_native, kwargs={"max_seconds": 240.0})
+            server.start()
+            ctx = mp.get_context("spawn")
+            q = ctx.Queue()
+            procs = [ctx.Process(target=_broker_rank, args=(name, r, P[r::3], q)) for r in range(3)]
+            for p in procs:
+                p.start()
+            got = {}
+            t0 = time.time()
+            while len(got) < 3 and time.time() - t0 < 240 and server.is_alive():
+                try:
+                    r, vals = q.get(timeout=0.2)
+                    got[r] = vals
+                except Exception:  # noqa: BLE001 - queue.Empty
+                    pass
+            b.stop()
+            server.join(timeout=60)
+            for p in procs:
+                p.join(timeout=30)
+            assert not server.is_alive() and len(got) == 3
+            for r in range(3):
+                assert got[r] == want[r::3]
+            assert b.stats["thetas"] == 30 and 1 <= b.stats["batches"] <= 30
+        # a context listed twice is refused before anything is served
+        with broker.LikelihoodBroker([fit, fit], name + "x", slots=2) as b2:
+            with pytest.raises(RuntimeError, match="listed twice"):
+                b2.serve_native(max_seconds=1.0)

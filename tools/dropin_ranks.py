@@ -113,20 +113,32 @@ def worker_threads(cfg, rank, nranks, calls, work, nthreads):
         json.dump(res, fh)
 
 
-def broker_server(cfg, name, slots, work):
-    """The one process with a device context: serves the clients' thetas in batches (mc-alf_amd/broker.py)."""
+def broker_server(cfg, name, slots, work, lanes=0):
+    """The one process with device contexts: serves the clients' thetas in batches (mc-alf_amd/broker.py).  lanes = 0: the
+    Python loop, one context; lanes >= 1: the loop inside the library (mcalf_broker_serve) over that many contexts."""
+    import threading
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     import mcalf_amd
     from mcalf_amd import broker, workloads
     from cases import oracle_synth
     kw, _, _ = workloads.config(cfg, oracle_synth)
-    fit = mcalf_amd.als_fitter(None, **kw)
-    with broker.LikelihoodBroker(fit, name, slots=slots) as b:
+    fits = [mcalf_amd.als_fitter(None, **kw) for _ in range(max(lanes, 1))]
+    stop_file = os.path.join(work, "stop")
+    with broker.LikelihoodBroker(fits, name, slots=slots) as b:
         open(os.path.join(work, "server_ready"), "w").close()
-        b.serve(stop_when=lambda: os.path.exists(os.path.join(work, "stop")))
+        if lanes == 0:
+            b.serve(stop_when=lambda: os.path.exists(stop_file), native=False)
+        else:
+            def watch():
+                while not os.path.exists(stop_file):
+                    time.sleep(0.01)
+                b.stop()
+            threading.Thread(target=watch, daemon=True).start()
+            b.serve_native()
         with open(os.path.join(work, "server.json"), "w") as fh:
             json.dump(b.stats, fh)
-    fit.close()
+    for f in fits:
+        f.close()
 
 
 def broker_client(cfg, rank, nranks, calls, work, name):
@@ -164,12 +176,12 @@ def broker_client(cfg, rank, nranks, calls, work, name):
         json.dump(res, fh)
 
 
-def run_broker(cfg, nranks, calls):
+def run_broker(cfg, nranks, calls, lanes=0):
     work = tempfile.mkdtemp(prefix="mcalf_broker_")
     name = "mcalf_dropin_%d" % os.getpid()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     me = os.path.abspath(__file__)
-    server = subprocess.Popen([sys.executable, me, "--broker-server", cfg, name, str(max(nranks, 1)), work], env=env)
+    server = subprocess.Popen([sys.executable, me, "--broker-server", cfg, name, str(max(nranks, 1)), work, str(lanes)], env=env)
     t0 = time.time()
     while not os.path.exists(os.path.join(work, "server_ready")):
         if time.time() - t0 > 300 or server.poll() is not None:
@@ -194,6 +206,7 @@ def run_broker(cfg, nranks, calls):
     st = json.load(open(os.path.join(work, "server.json")))
     same = all(r["shared_logL"] == res[0]["shared_logL"] for r in res)
     return {"ranks": nranks, "processes": nranks, "threads_per_process": 1, "broker": True, "calls_per_rank": calls,
+            "server_loop": "python, 1 context" if lanes == 0 else "library (mcalf_broker_serve), %d context(s)" % lanes,
             "thetas_per_launch": st["thetas"] / max(st["batches"], 1),
             "aggregate_logL_per_s": sum(r["calls"] / r["wall_s"] for r in res),
             "us_per_call_mean": sum(r["us_mean"] for r in res) / nranks,
@@ -232,7 +245,7 @@ def run(cfg, nranks, calls, nthreads=1):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--broker-server":
-        broker_server(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5])
+        broker_server(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5], int(sys.argv[6]) if len(sys.argv) > 6 else 0)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "--broker-client":
         broker_client(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], sys.argv[7])
@@ -253,7 +266,8 @@ def main():
     rows = []
     for spec in args.ranks.split(","):
         if spec.startswith("b"):                            # bR: R ranks WITHOUT device contexts behind one likelihood broker
-            rows.append(run_broker(args.config, int(spec[1:]), args.calls))
+            nr, _, ln = spec[1:].partition("l")             # (Python loop); bRlL: the library's loop over L contexts
+            rows.append(run_broker(args.config, int(nr), args.calls, int(ln) if ln else 0))
             continue
         pr, _, thr = spec.partition("x")
         rows.append(run(args.config, int(pr), args.calls, int(thr) if thr else 1))
@@ -264,7 +278,7 @@ def main():
     for r in rows:
         del r["shared_logL_rank0"]
         if r.get("broker"):
-            print("R = %d ranks behind ONE broker (%.1f thetas per launch):" % (r["ranks"], r["thetas_per_launch"]), end=" ")
+            print("R = %d ranks behind ONE broker [%s] (%.1f thetas per launch):" % (r["ranks"], r["server_loop"], r["thetas_per_launch"]), end=" ")
         print("R = %d (%d processes x %d threads): %.1f us per call (median %.1f, worst p99 %.1f), %.0f logL/s aggregate, bit-equal %s, |dlogL| vs oracle %.1e"
               % (r["ranks"], r["processes"], r["threads_per_process"], r["us_per_call_mean"], r["us_per_call_median"], r["us_per_call_p99_max"], r["aggregate_logL_per_s"],
                  r["bit_equal_across_ranks"], r["max_abs_dlogL_vs_oracle"]))
