@@ -36,6 +36,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.mcalf_line) == 24
     assert C.sizeof(_lib.mcalf_spec) == 8 + 3 * 8 + 8 + 8 + 8 + 24 + 4 * 4 + 3 * 8 + 2 * 4 + 8 + 2 * 8
     assert C.sizeof(_lib.mcalf_info_t) == 8 * 4 + 8 + 32
+    assert C.sizeof(_lib.mcalf_broker_t) == 2 * 4 + 10 * 8
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -102,5 +103,8 @@ def test_null_arguments_do_not_crash():
     assert lib.mcalf_info(None, None) == -1
     assert lib.mcalf_loglike_batch(None, None, 4, None) == -1
     assert lib.mcalf_reserve(None, 4) == -1
+    assert lib.mcalf_broker_serve(None, 0, None, 0.0) == -1
+    one = (C.c_void_p * 1)(None)
+    assert lib.mcalf_broker_serve(one, 1, None, 0.0) == -1
     assert lib.mcalf_voigt_hjerting(None, None, -1, None, -1) == -1
     assert lib.mcalf_voigt_hjerting(None, None, 0, None, -1) == 0
