@@ -210,7 +210,8 @@ typedef struct {
     int32_t inline_setup;   /* 1: small launch -- ONE kernel, the per-sample set-up ran inside the fused kernel */
     int32_t ordered;        /* 1: the persistent grid handed the live points out sorted by component count      */
     int32_t stream_setup_wgs; /* MCALF_PATH_HOST_STREAM: workgroups of the grid dedicated to the set-up while rows were outstanding */
-    int32_t stream_polled;  /* MCALF_PATH_HOST_STREAM: 1 = completion seen through the kernel's page-locked word, 0 = stream signal */
+    int32_t stream_polled;  /* MCALF_PATH_HOST_STREAM: 1 = completion seen through the kernel's page-locked word, 0 = stream signal;
+                               MCALF_PATH_HOST_ZEROCOPY: 1 = completion read off the results in page-locked memory */
 } mcalf_launch_info_t;
 int mcalf_last_launch(const mcalf_ctx* ctx, mcalf_launch_info_t* info);
 

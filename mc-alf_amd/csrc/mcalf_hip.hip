@@ -2517,6 +2517,10 @@ static int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t ba
     return MCALF_OK;
 }
 
+// What a result slot of the small-call block holds until its kernel has written it: a quiet NaN with a payload no
+// arithmetic produces (the kernels' NaNs are the canonical one or carry an operand's payload).
+constexpr uint64_t kResultPending = 0x7FF8C0DEC0DE0001ull;
+
 // The page-locked, device-mapped block small calls go through: parameters in its first half, results in its second.
 static int ensure_small(mcalf_ctx* ctx) {
     if (!ctx->h_small) {
@@ -2540,9 +2544,27 @@ static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
         if ((rc = ensure_small(ctx))) return rc;
         std::memcpy(ctx->h_small, P, (size_t)batch * rowlen * sizeof(double));
         ctx->last.path = MCALF_PATH_HOST_ZEROCOPY; ctx->last.pinned_in = ctx->last.pinned_out = 0;
+        // Completion is read off the results: their slots are filled with a NaN no kernel produces, and the call is over
+        // when none is left -- a stream wait costs an interrupt and a thread wake-up on top of the kernel, a fifth of a
+        // one-theta call.  (The stream is asked now and then, so that a failed launch cannot keep the call here.)
+        uint64_t* res = reinterpret_cast<uint64_t*>(ctx->h_small + kSmallDoubles);
+        const bool poll = ctx->stream_poll != 0;
+        if (poll)
+            for (int64_t i = 0; i < batch; ++i) __atomic_store_n(res + i, kResultPending, __ATOMIC_RELEASE);
         rc = launch(ctx, mode, ctx->d_small, batch, targonly, fill, ctx->d_small + kSmallDoubles, nullptr, ctx->stream);
         if (rc) return rc;
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        bool done = false;
+        if (poll) {
+            int64_t left = batch;                            // results [left, batch) have been seen
+            for (unsigned long spins = 1;; ++spins) {
+                while (left > 0 && __atomic_load_n(res + left - 1, __ATOMIC_ACQUIRE) != kResultPending) --left;
+                if (left == 0) { done = true; break; }
+                if ((spins & 0x3FFFul) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;
+                __builtin_ia32_pause();
+            }
+        }
+        if (!done) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->last.stream_polled = done ? 1 : 0;
         std::memcpy(out_scalar, ctx->h_small + kSmallDoubles, (size_t)batch * sizeof(double));
         return MCALF_OK;
     }
@@ -2614,7 +2636,7 @@ extern "C" int mcalf_broker_serve(mcalf_ctx* const* ctxs, int32_t nctx, const mc
     // launch, and the launch is over when none is left (the results land in page-locked memory; asking the runtime --
     // hipStreamQuery in a loop -- cost more per round than the Python loop's blocking wait).  The stream is asked only
     // now and then, so that a failed launch cannot keep the loop waiting.
-    constexpr uint64_t kPending = 0x7FF8C0DEC0DE0001ull;
+    constexpr uint64_t kPending = kResultPending;
     Lane lane[kMaxLanes];
     int rc;
     for (int k = 0; k < nctx; ++k) {

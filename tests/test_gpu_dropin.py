@@ -110,3 +110,27 @@ def test_the_librarys_broker_loop_over_two_contexts_gives_the_same_bits():
         with broker.LikelihoodBroker([fit, fit], name + "x", slots=2) as b2:
             with pytest.raises(RuntimeError, match="listed twice"):
                 b2.serve_native(max_seconds=1.0)
+
+
+@pytest.mark.parametrize("cfg", ["A", "B", "E"])
+def test_small_calls_read_their_completion_off_the_results(cfg, monkeypatch):
+    """One theta per call (and small batches) through the host-pointer entry: the call returns when every result slot of the
+    page-locked block has been written (no stream wait: `stream_polled`), with the bits the stream-wait form gives
+    (MCALF_STREAM_POLL=0) -- for a row of NaN parameters too (every term dropped by the nansum, hires_fitter.py:294)."""
+    kw, _, seed = workloads.config(cfg, oracle_synth)
+    P = workloads.draw_P(kw, 40, np.random.default_rng(seed + 11), damped=2 if cfg == "E" else 0)
+    P[7, 1:] = np.nan
+    got = {}
+    for poll in ("1", "0"):
+        monkeypatch.setenv("MCALF_STREAM_POLL", poll)
+        with mcalf_amd.als_fitter(None, **kw) as fit:
+            one = np.array([fit.lnlhood_dy(p) for p in P[:12]])
+            ll1 = fit.last_launch()
+            many = fit.loglike_batch(P)
+            ll = fit.last_launch()
+            assert ll.path == mcalf_amd._lib.MCALF_PATH_HOST_ZEROCOPY and ll.stream_polled == int(poll) == ll1.stream_polled
+            got[poll] = (one, many)
+    assert np.isfinite(np.delete(got["1"][1], 7)).all()
+    assert np.array_equal(got["1"][0], got["1"][1][:12], equal_nan=True)
+    for k in range(2):
+        assert np.array_equal(got["1"][k], got["0"][k], equal_nan=True)
