@@ -1446,6 +1446,7 @@ struct mcalf_ctx {
     bool profiling = false;
     // Small host-pointer calls (the one-theta-at-a-time solvers): parameters and results travel through a
     // page-locked, device-mapped staging block that the kernels read / write directly -- no copy commands.
+    std::vector<double> h_prior;        // the prior box as mcalf_set_prior took it: lo[ndim], hi[ndim] (host copy)
     double* h_small = nullptr;          // host address
     double* d_small = nullptr;          // the same memory as the device sees it
     // prior box of mcalf_set_prior (device copy in d_prior: lo[ndim] then hi[ndim])
@@ -2102,7 +2103,7 @@ static void stream_trace_report(const mcalf_ctx* ctx) {
 
 static int stream_prepare(mcalf_ctx* ctx, int mode, int64_t batch);
 static int stream_launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, double* d_out, hipStream_t stream, int wgs,
-                         int64_t eager_rows, bool staged, bool host_rows);
+                         int64_t eager_rows, bool staged, bool host_rows, bool from_cube = false);
 static bool stream_qualifies(const mcalf_ctx* ctx, int64_t batch);
 
 static int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill,
@@ -2368,8 +2369,10 @@ static int stream_prepare(mcalf_ctx* ctx, int mode, int64_t batch) {
 // rows PER XCD that any of its workgroups may set up; staged: the kernel waits for the host's row count
 // (ctx->h_ctl[kCtlArrived]).
 static int stream_launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, double* d_out, hipStream_t stream, int wgs,
-                         int64_t eager_rows, bool staged, bool host_rows) {
-    KArgs a = make_kargs(ctx, mode, dP, 0, batch, 0, 0, 0, d_out, nullptr, false, nullptr);
+                         int64_t eager_rows, bool staged, bool host_rows, bool from_cube) {
+    // (from_cube: the rows are unit-cube rows, mapped through the prior box while they are decoded; the transformed rows
+    // themselves, when the caller wants them, are formed on the host while the launch runs: host_scale_cube)
+    KArgs a = make_kargs(ctx, mode, dP, 0, batch, 0, 0, 0, d_out, nullptr, from_cube, nullptr);
     a.taps_shared = 0;                                    // (a row's stamp covers its own taps only)
     a.recs = ctx->s_recs; a.taps = ctx->s_taps; a.hdr = ctx->s_hdr;
     a.persist = 1;
@@ -2420,7 +2423,27 @@ static bool stream_qualifies(const mcalf_ctx* ctx, int64_t batch) {
     return ctx->persist && nitems >= 4 * slots && nitems <= 0x7fff0000LL && batch <= 0x7fff0000LL;
 }
 
-static int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, double* out_scalar, bool* taken) {
+// theta = cube * (hi - lo) + lo with the separately rounded multiply and add numpy performs (hires_fitter.py:206 / :214)
+// and int() on the ncomp slot (:207-208): the arithmetic of sample_param() / mcalf_scale_cube_kernel, on the host -- the
+// host-pointer cube entries form the rows they hand back while their launch runs.
+static void host_scale_cube(const mcalf_ctx* ctx, const double* cube, int64_t batch, double* theta) {
+    const int nd = ctx->ndim;
+    const double* lo = ctx->h_prior.data();
+    const double* hi = lo + nd;
+    for (int64_t r = 0; r < batch; ++r) {
+        const double* c = cube + (size_t)r * nd;
+        double* t = theta + (size_t)r * nd;
+        for (int d = 0; d < nd; ++d) {
+#pragma clang fp contract(off)
+            const double scaled = c[d] * (hi[d] - lo[d]);
+            t[d] = scaled + lo[d];
+        }
+        if (ctx->prior_int) t[ctx->startind] = std::trunc(t[ctx->startind]);
+    }
+}
+
+static int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, double* out_scalar, bool* taken,
+                           bool from_cube = false, double* theta_out = nullptr) {
     *taken = false;
     const bool trace = ctx->stream_trace;
     double tm[7] = {};
@@ -2466,7 +2489,7 @@ static int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t ba
     // the rows an XCD's first items need are set up by whichever of its workgroups gets there first, the rest by its
     // dedicated workgroups
     const int64_t eager_blocks = ctx->stream_eager > 0 ? ctx->stream_eager : (first_rows + 7) / 8;
-    if ((rc = stream_launch(ctx, mode, dP_view, batch, d_out_view, ctx->stream, wgs, eager_blocks, !pin_in, true)))
+    if ((rc = stream_launch(ctx, mode, dP_view, batch, d_out_view, ctx->stream, wgs, eager_blocks, !pin_in, true, from_cube)))
         return rc;
     const bool tiled = (mode == kModeLogL || mode == kModeChi2) && ctx->ntiles > 1;
     if (trace) tm[3] = now_us();
@@ -2480,6 +2503,7 @@ static int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t ba
             __atomic_store_n(const_cast<unsigned int*>(ctx->h_ctl + kCtlArrived), (unsigned int)(r0 + n), __ATOMIC_RELEASE);
         }
     }
+    if (theta_out) host_scale_cube(ctx, P, batch, theta_out);   // (under the launch)
     hipError_t he = hipGetLastError();
     if (trace) tm[4] = now_us();
     // Completion: the word the last workgroup writes once every result has been acknowledged (a stream wait costs an
@@ -2530,6 +2554,40 @@ static int ensure_small(mcalf_ctx* ctx) {
     return MCALF_OK;
 }
 
+// Small scalar-output calls (up to kSmallDoubles parameters: single-theta calls, config B's batch), zero-copy: a
+// single-theta call is dominated by the latency of its two copy commands.  from_cube / theta_out: as in run_host_stream.
+static int run_host_small(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
+                          double* out_scalar, bool from_cube, double* theta_out) {
+    int rc;
+    if ((rc = ensure_small(ctx))) return rc;
+    std::memcpy(ctx->h_small, P, (size_t)batch * rowlen * sizeof(double));
+    ctx->last.path = MCALF_PATH_HOST_ZEROCOPY; ctx->last.pinned_in = ctx->last.pinned_out = 0;
+    // Completion is read off the results: their slots are filled with a NaN no kernel produces, and the call is over
+    // when none is left -- a stream wait costs an interrupt and a thread wake-up on top of the kernel, a fifth of a
+    // one-theta call.  (The stream is asked now and then, so that a failed launch cannot keep the call here.)
+    uint64_t* res = reinterpret_cast<uint64_t*>(ctx->h_small + kSmallDoubles);
+    const bool poll = ctx->stream_poll != 0;
+    if (poll)
+        for (int64_t i = 0; i < batch; ++i) __atomic_store_n(res + i, kResultPending, __ATOMIC_RELEASE);
+    rc = launch(ctx, mode, ctx->d_small, batch, targonly, fill, ctx->d_small + kSmallDoubles, nullptr, ctx->stream, from_cube);
+    if (rc) return rc;
+    if (theta_out) host_scale_cube(ctx, P, batch, theta_out);       // (under the launch)
+    bool done = false;
+    if (poll) {
+        int64_t left = batch;                            // results [left, batch) have been seen
+        for (unsigned long spins = 1;; ++spins) {
+            while (left > 0 && __atomic_load_n(res + left - 1, __ATOMIC_ACQUIRE) != kResultPending) --left;
+            if (left == 0) { done = true; break; }
+            if ((spins & 0x3FFFul) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;
+            __builtin_ia32_pause();
+        }
+    }
+    if (!done) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->last.stream_polled = done ? 1 : 0;
+    std::memcpy(out_scalar, ctx->h_small + kSmallDoubles, (size_t)batch * sizeof(double));
+    return MCALF_OK;
+}
+
 // Host-pointer entries: stage through the context's workspaces on its private stream.
 static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
                     double* out_scalar, double* out_model) {
@@ -2539,35 +2597,8 @@ static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
     if (!P || (!out_scalar && !out_model)) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc;
-    if (out_scalar && !out_model && (size_t)batch * rowlen <= kSmallDoubles && (size_t)batch <= kSmallDoubles) {
-        // zero-copy path: a single-theta call is dominated by the latency of its two copy commands
-        if ((rc = ensure_small(ctx))) return rc;
-        std::memcpy(ctx->h_small, P, (size_t)batch * rowlen * sizeof(double));
-        ctx->last.path = MCALF_PATH_HOST_ZEROCOPY; ctx->last.pinned_in = ctx->last.pinned_out = 0;
-        // Completion is read off the results: their slots are filled with a NaN no kernel produces, and the call is over
-        // when none is left -- a stream wait costs an interrupt and a thread wake-up on top of the kernel, a fifth of a
-        // one-theta call.  (The stream is asked now and then, so that a failed launch cannot keep the call here.)
-        uint64_t* res = reinterpret_cast<uint64_t*>(ctx->h_small + kSmallDoubles);
-        const bool poll = ctx->stream_poll != 0;
-        if (poll)
-            for (int64_t i = 0; i < batch; ++i) __atomic_store_n(res + i, kResultPending, __ATOMIC_RELEASE);
-        rc = launch(ctx, mode, ctx->d_small, batch, targonly, fill, ctx->d_small + kSmallDoubles, nullptr, ctx->stream);
-        if (rc) return rc;
-        bool done = false;
-        if (poll) {
-            int64_t left = batch;                            // results [left, batch) have been seen
-            for (unsigned long spins = 1;; ++spins) {
-                while (left > 0 && __atomic_load_n(res + left - 1, __ATOMIC_ACQUIRE) != kResultPending) --left;
-                if (left == 0) { done = true; break; }
-                if ((spins & 0x3FFFul) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;
-                __builtin_ia32_pause();
-            }
-        }
-        if (!done) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->last.stream_polled = done ? 1 : 0;
-        std::memcpy(out_scalar, ctx->h_small + kSmallDoubles, (size_t)batch * sizeof(double));
-        return MCALF_OK;
-    }
+    if (out_scalar && !out_model && (size_t)batch * rowlen <= kSmallDoubles && (size_t)batch <= kSmallDoubles)
+        return run_host_small(ctx, mode, P, batch, rowlen, targonly, fill, out_scalar, false, nullptr);
     if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, (size_t)batch * rowlen))) return rc;
     if (out_scalar && (rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
     if (out_model && (rc = grow(ctx, &ctx->d_model, &ctx->cap_model, (size_t)batch * ctx->npix))) return rc;
@@ -2983,6 +3014,8 @@ extern "C" int mcalf_set_prior(mcalf_ctx* ctx, const double* lo, const double* h
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->d_prior, lo, ctx->ndim * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->d_prior + ctx->ndim, hi, ctx->ndim * sizeof(double), hipMemcpyHostToDevice));
+    ctx->h_prior.assign(lo, lo + ctx->ndim);
+    ctx->h_prior.insert(ctx->h_prior.end(), hi, hi + ctx->ndim);
     ctx->prior_set = true;
     ctx->prior_int = int_ncomp ? 1 : 0;
     return MCALF_OK;
@@ -3007,6 +3040,16 @@ extern "C" int mcalf_loglike_cube_batch(mcalf_ctx* ctx, const double* cube, int6
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t total = (size_t)batch * ctx->ndim;
     int rc;
+    // the paths of mcalf_loglike_batch, with the prior transform applied while the rows are decoded and the transformed
+    // rows formed on the host under the launch: the zero-copy small call, ONE streaming launch for large batches
+    if (total <= kSmallDoubles && (size_t)batch <= kSmallDoubles)
+        return run_host_small(ctx, kModeLogL, cube, batch, ctx->ndim, 0, 0, logL, true, theta);
+    {
+        bool taken = false;
+        if ((rc = run_host_stream(ctx, kModeLogL, cube, batch, ctx->ndim, logL, &taken, true, theta)) != MCALF_OK || taken) return rc;
+    }
+    // otherwise (tiled spectra, explicit row blocks): staged copies, the transformed rows come back from the device
+    ctx->last.path = MCALF_PATH_HOST_STAGED; ctx->last.pinned_in = ctx->last.pinned_out = 0;
     if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, total))) return rc;
     if ((rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
     if (theta && (rc = grow(ctx, &ctx->d_model, &ctx->cap_model, total))) return rc;

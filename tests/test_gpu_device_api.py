@@ -118,6 +118,29 @@ def test_cube_in_logl_out_matches_two_step_path_and_oracle():
     assert np.max(np.abs(logL[:40] - want)) < 1e-4
 
 
+@pytest.mark.parametrize("cfg,n,path", [("C", 4096, "stream"), ("C", 700, "small"), ("E", 1400, "staged")])
+def test_cube_host_entry_takes_the_fast_paths_of_the_theta_entry(cfg, n, path):
+    """The host-pointer cube entry goes the ways of mcalf_loglike_batch -- ONE streaming launch for a large batch of a
+    single-tile spectrum, the zero-copy small call below 512 KB of parameters (completion read off the results), staged
+    copies for a tiled spectrum -- with the prior transform applied while the rows are decoded and theta formed on the
+    host under the launch: theta bit-equal to the numpy transform, logL bit-equal to the two-step path, both int() flavours."""
+    kw, _, seed = workloads.config(cfg, oracle_synth)
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        cubes = np.random.default_rng(seed + 300).random((n, fit.ndim))
+        for int_ncomp in (True, False):
+            theta, logL = fit.loglike_cube_batch(cubes, int_ncomp=int_ncomp)
+            ll = fit.last_launch()
+            assert ll.path == {"stream": _lib.MCALF_PATH_HOST_STREAM, "small": _lib.MCALF_PATH_HOST_ZEROCOPY,
+                               "staged": _lib.MCALF_PATH_HOST_STAGED}[path]
+            if path != "staged":
+                assert ll.stream_polled == 1
+            want_theta = (np.array([fit._scale_cube_pc(c.copy()) for c in cubes]) if int_ncomp else
+                          np.array([fit._scale_cube_mn(c.copy(), fit.ndim, fit.ndim) for c in cubes]))
+            assert np.array_equal(theta, want_theta)
+            assert np.array_equal(logL, fit.loglike_batch(np.array([fit._scale_cube_pc(c.copy()) for c in cubes])))
+            assert np.array_equal(fit.loglike_cube_batch(cubes, int_ncomp=int_ncomp, return_theta=False), logL)
+
+
 def test_cube_entry_requires_a_prior():
     kw, _, _ = workloads.config("A")
     with mcalf_amd.als_fitter(None, **kw) as fit:

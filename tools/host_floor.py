@@ -7,6 +7,8 @@ One config (default C).  Per variant the median of repeated passes of K steps:
                  of a step whose inputs never move -- the floor of any host-pointer entry
   host_pageable  mcalf_loglike_batch from pageable numpy arrays
   host_pinned    mcalf_loglike_batch from page-locked arrays
+  cube_host      mcalf_loglike_cube_batch from pageable unit cubes: prior transform while the rows are decoded, theta
+                 formed on the host under the launch (MCALF_STREAM=0: the staged form, theta back from the device)
   memcpy         a plain numpy copy of P into a page-locked block (what one host thread needs to stage the batch)
   zero_copy_read the set-up + fused kernels reading P straight from a page-locked, device-mapped block (device entry
                  given the mapped pointer): PCIe reads by the kernels instead of a copy command
@@ -54,6 +56,7 @@ def main():
     P_pin, out_pin = P_pin_t.numpy(), out_pin_t.numpy()
     out_host = np.empty(batch)
     stage = torch.empty(P.shape, dtype=torch.float64).pin_memory().numpy()
+    cubes = np.random.default_rng(seed + 1).random(P.shape)
 
     def dev_async():
         launch(ctx, dP.data_ptr(), batch, out_d.data_ptr(), st)
@@ -72,6 +75,8 @@ def main():
         "device_sync": dev_sync,
         "host_pageable": lambda: fit.loglike_batch(P, out=out_host),
         "host_pinned": lambda: fit.loglike_batch(P_pin, out=out_pin),
+        "cube_host": lambda: fit.loglike_cube_batch(cubes),                       # unit cubes in, (theta, logL) out
+        "cube_host_no_theta": lambda: fit.loglike_cube_batch(cubes, return_theta=False),
         "memcpy": lambda: np.copyto(stage, P),
         "zero_copy_read": zero_copy,
     }
