@@ -481,6 +481,7 @@ def main():
                     "bit_equal_to_device_entry": same,
                     "bit_equal_to_device_entry_pinned": bool(np.array_equal(out_pin, logL_dev)),
                     "path": {_lib.MCALF_PATH_HOST_STREAM: "one streaming launch (MCALF_PATH_HOST_STREAM)",
+                             _lib.MCALF_PATH_HOST_ZEROCOPY: "zero-copy small call, completion read off the results (MCALF_PATH_HOST_ZEROCOPY)",
                              _lib.MCALF_PATH_HOST_PIPELINED: "row-block pipeline (MCALF_PATH_HOST_PIPELINED)"}.get(llh.path, str(llh.path)),
                     "stream_setup_workgroups": llh.stream_setup_wgs, "completion_polled": bool(llh.stream_polled),
                     "what": "mcalf_loglike_batch: P [batch][ndim] f64 from host memory and logL [batch] f64 back to host memory "
@@ -515,6 +516,14 @@ def main():
         ncD = PD[:, fit.startind].astype(int)
         strong_ref = {"workload": WORKLOAD_LABEL["D"] + ", all rows on ONE GPU", "global_batch": batchD, "steps": kD,
                       "ms_per_step": tD / kD * 1e3, "value": float(ncD.sum()) * npix * kD / tD}
+        if not args.no_host_api:
+            # the same rows through the host-pointer entry (pageable arrays): the fixed cost of a synchronous call and of
+            # the streaming launch's start, spread over eight times the rows
+            outDh = np.empty(batchD)
+            fit.loglike_batch(PD, out=outDh)
+            tDh, _ = measure(lambda: fit.loglike_batch(PD, out=outDh), kD, red_dev)
+            strong_ref["host_api"] = {"ms_per_step": tDh / kD * 1e3, "host_over_device": tDh / tD,
+                                      "bit_equal_to_device_entry": bool(np.array_equal(outDh, outD.cpu().numpy()))}
         del dPD, outD
 
     # Model-output entry (reconstruct_spec for the whole batch, hires_fitter.py:409-449; consumer cli.py:414-418):

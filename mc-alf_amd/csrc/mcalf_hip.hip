@@ -2548,7 +2548,8 @@ constexpr uint64_t kResultPending = 0x7FF8C0DEC0DE0001ull;
 // The page-locked, device-mapped block small calls go through: parameters in its first half, results in its second.
 static int ensure_small(mcalf_ctx* ctx) {
     if (!ctx->h_small) {
-        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_small, 2 * kSmallDoubles * sizeof(double), hipHostMallocMapped));
+        // (coherent: the host fills the result slots before a launch and reads them while it runs)
+        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_small, 2 * kSmallDoubles * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
         HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->d_small, ctx->h_small, 0));
     }
     return MCALF_OK;
