@@ -495,6 +495,16 @@ def main():
         for _ in range(500):
             fit.lnlhood_dy(th)
         host_api["single_call_us"] = (time.perf_counter() - t1) / 500 * 1e6
+        # the same through the resident evaluator (mcalf_set_resident: no launch per call; opt-in)
+        if fit.info.ntiles == 1 and fit.ndim <= 64:
+            fit.set_resident(500)
+            for _ in range(50):
+                fit.lnlhood_dy(th)
+            t1 = time.perf_counter()
+            for _ in range(500):
+                fit.lnlhood_dy(th)
+            host_api["single_call_us_resident"] = (time.perf_counter() - t1) / 500 * 1e6
+            fit.set_resident(0)
 
     # N = 1 leg of the strong-scaling job: config D's 32768 rows on this one GPU
     strong_ref = None

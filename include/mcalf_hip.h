@@ -40,9 +40,10 @@
 extern "C" {
 #endif
 
-#define MCALF_ABI_VERSION 4   /* 2: mcalf_last_launch, gatherv / overlap / join, version string carries the source hash
+#define MCALF_ABI_VERSION 5   /* 2: mcalf_last_launch, gatherv / overlap / join, version string carries the source hash
                                  3: MCALF_PATH_HOST_STREAM, mcalf_launch_info_t grows by stream_setup_wgs / stream_polled
-                                 4: mcalf_broker_serve */
+                                 4: mcalf_broker_serve
+                                 5: mcalf_set_resident */
 
 enum {
     MCALF_OK = 0,
@@ -137,6 +138,16 @@ int mcalf_chi2_batch(mcalf_ctx* ctx, const double* P, int64_t batch, double* chi
  * alone (the per-line model calc_w integrates, hires_fitter.py:483). */
 int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batch, int32_t which, double* flux);
 
+/* Resident one-theta evaluator (off by default).  The solvers call the likelihood one theta at a time (lnlhood_pc / _dy /
+ * _mn: hires_fitter.py:250-285); of such a call about a third is the kernel LAUNCH, and launches of different processes
+ * serialise.  With idle_us > 0, mcalf_loglike_batch calls of ONE row on a spectrum that fits one pixel tile are answered by
+ * one workgroup that STAYS on the chip between calls and takes its requests from a page-locked mailbox -- same arithmetic,
+ * same bits, no launch.  The kernel leaves by itself after idle_us microseconds without a request (the next call starts
+ * another one), so a device-wide synchronisation never waits longer than that; idle_us = 0 tells it to leave now and turns
+ * the mode off.  Other entries of the context are not affected (the evaluator has its own stream and its own memory).
+ * The environment variable MCALF_RESIDENT_US gives the initial value. */
+int mcalf_set_resident(mcalf_ctx* ctx, int32_t idle_us);
+
 /* Likelihood broker, serving side: MANY one-theta-at-a-time solver ranks (PolyChord runs one MPI rank per core, each calling
  * lnlhood_pc(theta) serially: cli.py:37-41, 110; hires_fitter.py:250-262) served by ONE thread of ONE process that owns the
  * device contexts.  The request block lives wherever the caller puts it (mc-alf_amd/broker.py: POSIX shared memory); rank s
@@ -207,7 +218,8 @@ typedef struct {
     int32_t selfhalo;       /* 1: single-tile spectrum, halo entries are copies of the tile's own pixels      */
     int32_t pinned_in;      /* host-pointer entries: the parameter rows were page-locked caller memory        */
     int32_t pinned_out;     /* host-pointer entries: the result array was page-locked caller memory           */
-    int32_t inline_setup;   /* 1: small launch -- ONE kernel, the per-sample set-up ran inside the fused kernel */
+    int32_t inline_setup;   /* 1: small launch -- ONE kernel, the per-sample set-up ran inside the fused kernel;
+                               3: no launch at all -- the context's resident evaluator answered (mcalf_set_resident) */
     int32_t ordered;        /* 1: the persistent grid handed the live points out sorted by component count      */
     int32_t stream_setup_wgs; /* MCALF_PATH_HOST_STREAM: workgroups of the grid dedicated to the set-up while rows were outstanding */
     int32_t stream_polled;  /* MCALF_PATH_HOST_STREAM: 1 = completion seen through the kernel's page-locked word, 0 = stream signal;

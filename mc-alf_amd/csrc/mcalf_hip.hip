@@ -1329,7 +1329,9 @@ __device__ __forceinline__ void fused_items(const KArgs& a, double* smem) {
                 // (streaming launch: the result goes to page-locked host memory and the host reads it as soon as the
                 // launch's completion word says so, ahead of the end-of-kernel cache write-back: a system-scope store,
                 // written through -- plain stores were seen to linger in one XCD's L2 past the completion word)
-                if (kStream) __hip_atomic_store(a.out + s, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // (one-launch variant: its results go to page-locked memory too, and the host -- or, for the resident
+                // kernel below, the next request -- reads them while the kernel is still there)
+                if (kStream || kInline) __hip_atomic_store(a.out + s, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 else a.out[s] = val;
             } else {
                 double* pr = a.partial + ((size_t)s * a.ntiles + tileIdx) * 4;
@@ -1363,6 +1365,87 @@ __global__ __launch_bounds__(kBlock, kMinWaves) void mcalf_fused_kernel(const KA
         fused_items<kZeroPad, kSelfHalo, kLinesPerSync, kInline, kStream>(fresh, smem);
     } else {
         fused_items<kZeroPad, kSelfHalo, kLinesPerSync, kInline, kStream>(a, smem);
+    }
+}
+
+// RESIDENT one-theta evaluator (opt-in: mcalf_set_resident).  The solvers call the likelihood one theta at a time
+// (lnlhood_pc / _dy / _mn, hires_fitter.py:250-285), and of such a call's 18 us only 11 are the kernel: the rest is the
+// launch -- and launches of different processes serialise at 8.5 us each.  So ONE workgroup stays on the chip between calls
+// and takes its requests from a page-locked mailbox: the host writes the row and bumps `req`; thread 0 polls `req` (a PCIe
+// read per look), the workgroup copies the row into LDS with system-scope loads (nothing of a request is ever read
+// through a cache), runs the one-launch variant's item on it -- same code, same bits -- and the result goes out as a
+// system-scope store, followed by `ack`.  The kernel LEAVES after `idle_ticks` without a request (or when told to):
+// state = leaving, one more look at `req` (a request that slipped in is served, state = running again), state = gone.
+// The host treats "gone" as "launch another one"; a request posted behind the last look is therefore never lost, and no
+// wave can stay behind: every wait is bounded by the idle limit.
+constexpr unsigned kResRunning = 1u, kResLeaving = 2u, kResGone = 3u;
+constexpr int kResRowMax = 64;
+struct alignas(64) ResidentBox {
+    unsigned int req;            // host: number of the request whose row is in `row` (written last, release)
+    unsigned int quit;           // host: non-zero = leave at the next look
+    unsigned int ack;            // device: number of the last request answered
+    unsigned int state;          // device: kResRunning / kResLeaving / kResGone
+    double result;               // device; the host fills it with kResultPending before it posts a request
+    double pad[5];
+    double row[kResRowMax];      // host: the parameter row
+};
+template <bool kZeroPad, bool kSelfHalo>
+__global__ __launch_bounds__(kBlock, 2) void mcalf_resident_kernel(const KArgs a, ResidentBox* box, unsigned first,
+                                                                           long long idle_ticks, int row_offset_doubles) {
+    extern __shared__ __align__(16) double smem[];
+    double* sRow = smem + row_offset_doubles;            // behind everything the item uses
+    unsigned* sCtl = reinterpret_cast<unsigned*>(sRow + kResRowMax);
+    const int tid = threadIdx.x;
+    unsigned seen = first - 1u;
+    while (true) {
+        if (tid == 0) {
+            unsigned r;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (true) {
+                // (`req` and `quit` share eight bytes: ONE PCIe read per look)
+                const unsigned long long both = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&box->req), __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_SYSTEM);
+                r = (unsigned)both;
+                if (r != seen) break;
+                const bool told = (unsigned)(both >> 32) != 0u;
+                if (told || (long long)(__builtin_amdgcn_s_memrealtime() - t0) > idle_ticks) {
+                    __hip_atomic_store(&box->state, kResLeaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    stream_stores_done();                // (a read does not pass the posted write: the host has "leaving" before this look)
+                    r = __hip_atomic_load(&box->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (r != seen) { __hip_atomic_store(&box->state, kResRunning, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+                    __hip_atomic_store(&box->state, kResGone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            sCtl[0] = r;
+        }
+        __syncthreads();
+        const unsigned r = sCtl[0];
+        __syncthreads();
+        if (r == seen) return;                           // (workgroup-uniform) gone
+        // the row, past every cache
+        if (tid < kResRowMax) {
+            const unsigned long long bits = __hip_atomic_load(reinterpret_cast<unsigned long long*>(box->row) + tid, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_SYSTEM);
+            sRow[tid] = __builtin_bit_cast(double, bits);
+        }
+        __syncthreads();
+        // (the arguments are read afresh from the kernel-argument segment for every request, as in the streaming launch:
+        // kept alive across the waiting loop they cost the item 150 scalar spills)
+        typedef __attribute__((address_space(4))) const KArgs ArgSeg;
+        ArgSeg* kp = (ArgSeg*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        KArgs b = *(const KArgs*)kp;
+        b.P = sRow;
+        b.out = &box->result;
+        fused_items<kZeroPad, kSelfHalo, 4, true, false>(b, smem);
+        if (tid == 0) {                                  // (thread 0 stored the result itself)
+            stream_stores_done();
+            __hip_atomic_store(&box->ack, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        seen = r;
+        __syncthreads();
     }
 }
 
@@ -1446,6 +1529,15 @@ struct mcalf_ctx {
     bool profiling = false;
     // Small host-pointer calls (the one-theta-at-a-time solvers): parameters and results travel through a
     // page-locked, device-mapped staging block that the kernels read / write directly -- no copy commands.
+    // Resident one-theta evaluator (mcalf_set_resident; off by default): its mailbox, its own stream, what the host
+    // believes about the kernel, the next request number
+    ResidentBox* h_box = nullptr;       // page-locked, coherent, device-mapped
+    ResidentBox* d_box = nullptr;
+    hipStream_t res_stream = nullptr;
+    int resident_us = 0;                // idle limit in microseconds; 0 = no resident kernel
+    bool res_alive = false;
+    unsigned res_seq = 0;
+    long res_launches = 0, res_calls = 0;
     std::vector<double> h_prior;        // the prior box as mcalf_set_prior took it: lo[ndim], hi[ndim] (host copy)
     double* h_small = nullptr;          // host address
     double* d_small = nullptr;          // the same memory as the device sees it
@@ -1587,12 +1679,16 @@ static inline double now_us() {
 }
 
 static void stream_trace_report(const mcalf_ctx* ctx);
+static void resident_stop(mcalf_ctx* ctx);
 
 extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     if (!ctx) return;
     stream_trace_report(ctx);
     (void)hipSetDevice(ctx->device);
     comm_release(ctx);
+    resident_stop(ctx);
+    if (ctx->res_stream) (void)hipStreamDestroy(ctx->res_stream);
+    if (ctx->h_box) (void)hipHostFree((void*)ctx->h_box);
     void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_err, ctx->d_tabs, ctx->d_lines, ctx->d_wtab, ctx->d_segok,
                     ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds, ctx->d_prior, ctx->d_recs, ctx->d_taps, ctx->d_hdr,
                     ctx->d_queue, ctx->d_order, ctx->d_sws};
@@ -1865,6 +1961,7 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         if (const char* oe = std::getenv("MCALF_ORDER")) ctx->ordered = std::atoi(oe) != 0;
         ctx->inline_max_items = 2 * ctx->num_cu;                    // launches that fit the chip in one round of workgroups
         if (const char* ie = std::getenv("MCALF_INLINE_MAX")) ctx->inline_max_items = std::max(0, std::atoi(ie));
+        if (const char* re = std::getenv("MCALF_RESIDENT_US")) ctx->resident_us = std::min(1000000, std::max(0, std::atoi(re)));
         if (const char* sb = std::getenv("MCALF_SETUP_BLOCK")) {      // diagnostic: geometry of the set-up kernel
             const int v = std::atoi(sb);
             if (v >= 64 && v <= kSetupBlockMax && v % 64 == 0) ctx->setup_block = v;
@@ -2555,11 +2652,111 @@ static int ensure_small(mcalf_ctx* ctx) {
     return MCALF_OK;
 }
 
+// ---- resident one-theta evaluator, host side (device side: mcalf_resident_kernel) -------------------------------------
+static const void* resident_kernel_ptr(bool jax, bool selfhalo) {
+    if (jax) return selfhalo ? reinterpret_cast<const void*>(&mcalf_resident_kernel<true, true>)
+                             : reinterpret_cast<const void*>(&mcalf_resident_kernel<true, false>);
+    return selfhalo ? reinterpret_cast<const void*>(&mcalf_resident_kernel<false, true>)
+                    : reinterpret_cast<const void*>(&mcalf_resident_kernel<false, false>);
+}
+
+// Tell the resident kernel to leave and wait until it has (bounded by its own idle limit).
+static void resident_stop(mcalf_ctx* ctx) {
+    if (!ctx->h_box || !ctx->res_stream) return;
+    if (ctx->res_alive) {
+        __atomic_store_n(&ctx->h_box->quit, 1u, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(ctx->res_stream);
+        ctx->res_alive = false;
+    }
+}
+
+static bool resident_serves(const mcalf_ctx* ctx, int mode, int64_t batch, int rowlen, bool from_cube) {
+    return ctx->resident_us > 0 && mode == kModeLogL && batch == 1 && ctx->ntiles == 1 && rowlen <= kResRowMax && !from_cube &&
+           !ctx->profiling;
+}
+
+// One theta through the resident kernel: post the request (launching the kernel when there is none), spin on the result.
+static int resident_call(mcalf_ctx* ctx, const double* row, int rowlen, double* out) {
+    if (!ctx->h_box) {
+        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_box, sizeof(ResidentBox), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset((void*)ctx->h_box, 0, sizeof(ResidentBox));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->d_box, (void*)ctx->h_box, 0));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->res_stream, hipStreamNonBlocking));
+        const void* k = resident_kernel_ptr(ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX, ctx->selfhalo != 0);
+        HIP_TRY(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsBudget + 1024)));
+    }
+    ResidentBox* box = ctx->h_box;
+    uint64_t* res = reinterpret_cast<uint64_t*>(&box->result);
+    __atomic_store_n(res, kResultPending, __ATOMIC_RELAXED);
+    std::memcpy(box->row, row, (size_t)rowlen * sizeof(double));
+    const unsigned seq = ++ctx->res_seq;
+    ctx->last.path = MCALF_PATH_HOST_ZEROCOPY; ctx->last.pinned_in = ctx->last.pinned_out = 0;
+    ctx->last.persistent = 0; ctx->last.grid = 1; ctx->last.items = 1; ctx->last.inline_setup = 3; ctx->last.stream_polled = 1;
+    ctx->res_calls++;
+    auto launch_kernel = [&]() -> int {
+        // (a previous kernel of this context has said "gone", or there was none: a new one starts behind it on the stream)
+        KArgs a = make_kargs(ctx, kModeLogL, nullptr, 0, 1, 0, 0, 0, nullptr, nullptr, false, nullptr);
+        a.persist = 0; a.order = nullptr;
+        __atomic_store_n(&box->state, kResRunning, __ATOMIC_RELAXED);
+        __atomic_store_n(&box->quit, 0u, __ATOMIC_RELAXED);
+        __atomic_store_n(&box->req, seq, __ATOMIC_RELEASE);
+        ResidentBox* dbox = ctx->d_box;
+        unsigned first = seq;
+        long long idle = (long long)ctx->resident_us * 100;                  // ticks of the 100 MHz clock
+        int row_off = (int)((ctx->lds_bytes_inline / sizeof(double) + 1) & ~(size_t)1);
+        void* kargs[] = {(void*)&a, (void*)&dbox, (void*)&first, (void*)&idle, (void*)&row_off};
+        const size_t lds = (size_t)row_off * sizeof(double) + kResRowMax * sizeof(double) + 16;
+        HIP_TRY(ctx, hipLaunchKernel(resident_kernel_ptr(ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX, ctx->selfhalo != 0), dim3(1), dim3(kBlock),
+                                     kargs, lds, ctx->res_stream));
+        ctx->res_alive = true;
+        ctx->res_launches++;
+        return MCALF_OK;
+    };
+    int rc;
+    if (!ctx->res_alive) { if ((rc = launch_kernel())) return rc; }
+    else __atomic_store_n(&box->req, seq, __ATOMIC_RELEASE);
+    const double t0 = now_us();
+    for (unsigned long spins = 1;; ++spins) {
+        if (__atomic_load_n(res, __ATOMIC_ACQUIRE) != kResultPending) break;
+        if (__atomic_load_n(&box->state, __ATOMIC_ACQUIRE) == kResGone) {
+            // the kernel left without having seen this request (it looks once more after saying "leaving", so a request it
+            // has seen is answered): a new one takes it
+            if (__atomic_load_n(res, __ATOMIC_ACQUIRE) != kResultPending) break;
+            ctx->res_alive = false;
+            if ((rc = launch_kernel())) return rc;
+        }
+        if ((spins & 0xFFFFul) == 0) {
+            const hipError_t q = hipStreamQuery(ctx->res_stream);
+            if (q != hipSuccess && q != hipErrorNotReady) {
+                ctx->res_alive = false;
+                return set_err(ctx, MCALF_ERR_HIP, "resident evaluator failed: %s", hipGetErrorString(q));
+            }
+            if (now_us() - t0 > 5e6) {
+                ctx->res_alive = false;
+                return set_err(ctx, MCALF_ERR_HIP, "resident evaluator did not answer within 5 s");
+            }
+        }
+        __builtin_ia32_pause();
+    }
+    *out = box->result;
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_set_resident(mcalf_ctx* ctx, int32_t idle_us) {
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    if (idle_us < 0 || idle_us > 1000000) return set_err(ctx, MCALF_ERR_INVALID, "idle limit must be 0 (off) .. 1000000 us");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (idle_us == 0) resident_stop(ctx);
+    ctx->resident_us = idle_us;
+    return MCALF_OK;
+}
+
 // Small scalar-output calls (up to kSmallDoubles parameters: single-theta calls, config B's batch), zero-copy: a
 // single-theta call is dominated by the latency of its two copy commands.  from_cube / theta_out: as in run_host_stream.
 static int run_host_small(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
                           double* out_scalar, bool from_cube, double* theta_out) {
     int rc;
+    if (resident_serves(ctx, mode, batch, rowlen, from_cube)) return resident_call(ctx, P, rowlen, out_scalar);
     if ((rc = ensure_small(ctx))) return rc;
     std::memcpy(ctx->h_small, P, (size_t)batch * rowlen * sizeof(double));
     ctx->last.path = MCALF_PATH_HOST_ZEROCOPY; ctx->last.pinned_in = ctx->last.pinned_out = 0;

@@ -269,6 +269,12 @@ class als_fitter:
     def chunks_for(self, batch):
         return int(self._lib.mcalf_get_chunks(self._ctx, int(batch)))
 
+    def set_resident(self, idle_us):
+        """Resident one-theta evaluator (mcalf_set_resident): with `idle_us` > 0 the one-theta callables are answered by a
+        workgroup that stays on the GPU between calls -- no kernel launch per call -- and leaves by itself after `idle_us`
+        microseconds without one; 0 turns it off.  Same bits as the launched form."""
+        _lib.check(self._lib.mcalf_set_resident(self._ctx, int(idle_us)), self._ctx)
+
     def last_launch(self):
         """What the last call of this context did (`mcalf_last_launch`): entry plan, row blocks, whether the fused
         kernel ran as the persistent grid, its grid and work-item count."""
