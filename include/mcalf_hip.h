@@ -43,7 +43,7 @@ extern "C" {
 #define MCALF_ABI_VERSION 5   /* 2: mcalf_last_launch, gatherv / overlap / join, version string carries the source hash
                                  3: MCALF_PATH_HOST_STREAM, mcalf_launch_info_t grows by stream_setup_wgs / stream_polled
                                  4: mcalf_broker_serve
-                                 5: mcalf_set_resident */
+                                 5: mcalf_set_resident, mcalf_broker_serve_resident */
 
 enum {
     MCALF_OK = 0,
@@ -170,6 +170,21 @@ typedef struct {
     double idle_sleep_after_s;  /* spin this long without a request before yielding the core between polls */
 } mcalf_broker_t;
 int mcalf_broker_serve(mcalf_ctx* const* ctxs, int32_t nctx, const mcalf_broker_t* b, double max_seconds);
+
+/* The broker with RESIDENT evaluators: every solver rank gets a workgroup that stays on the chip and takes the rank's requests
+ * straight from its mailbox in the shared block -- no server thread and no launch on a call's path.  `boxes` points to `slots`
+ * mailboxes of MCALF_MAILBOX_BYTES each (64-byte aligned, zero-filled by whoever creates the block), laid out as
+ *   uint32 req, quit, ack, state;  double result;  double reserved[5];  double row[64]
+ * Rank s: result <- the bit pattern MCALF_RESULT_PENDING, row <- theta, then req <- req + 1 (in that order; a release store);
+ * spin until result differs from the pattern.  This call page-locks the block (hipHostRegister) and keeps ONE launch of
+ * `slots` workgroups alive while requests come (workgroup k polls mailbox k; they leave TOGETHER after idle_us without a
+ * request on any mailbox, and the next request starts the launch again -- one launch on one stream, because hardware queues
+ * are few); it returns when *stop becomes non-zero (every workgroup has left by then) or after max_seconds (0: never).  Serves spectra of one pixel tile with at
+ * most 64 parameters (MCALF_ERR_RANGE otherwise: use mcalf_broker_serve). */
+#define MCALF_MAILBOX_BYTES 576
+#define MCALF_RESULT_PENDING 0x7FF8C0DEC0DE0001ull
+int mcalf_broker_serve_resident(mcalf_ctx* ctx, void* boxes, int32_t slots, volatile uint64_t* stop, int32_t idle_us,
+                                uint64_t* stats, double max_seconds);
 
 /* Row blocks a batch is issued in (0 = automatic [default], n <= 8 = exactly n).  Automatic means ONE block
  * for the *_device entries (the persistent fused kernel leaves no launch tail worth filling; measured) and, for

@@ -132,6 +132,7 @@ SYMBOLS = {
     "mcalf_loglike_cube_batch": (C.c_int, [_CTX, _PD, C.c_int64, _PD, _PD]),
     "mcalf_loglike_cube_batch_device": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcalf_set_resident": (C.c_int, [_CTX, C.c_int32]),
+    "mcalf_broker_serve_resident": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_double]),
     "mcalf_broker_serve": (C.c_int, [C.POINTER(_CTX), C.c_int32, C.POINTER(mcalf_broker_t), C.c_double]),
     "mcalf_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mcalf_comm_init": (C.c_int, [_CTX, C.c_void_p, C.c_int32, C.c_int32]),

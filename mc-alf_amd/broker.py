@@ -20,6 +20,12 @@ interpreter in the round), and with SEVERAL contexts of the same problem (`Likel
 requests that arrive while a launch is in flight leave at once on the next free context instead of waiting for it to
 end.  `poll()` / `serve(native=False)` are the same protocol in Python, for any object with `loglike_batch`.
 
+`LikelihoodBroker(fit, name, slots, resident_us=500)` goes one step further for spectra of one pixel tile: every rank gets
+a WORKGROUP that stays on the GPU and takes the rank's requests straight from its mailbox in the shared block
+(`mcalf_broker_serve_resident`; the block is page-locked by the server).  No server thread and no kernel launch is on a
+call's path any more -- the server only restarts the launch of those workgroups when a request finds none (they leave,
+together, after `resident_us` microseconds without a request from any rank).  Same client class, same callables, same bits.
+
 The client mirrors the solver-facing callables of `als_fitter` (lnlhood_pc / _dy / _mn / lnlhood_worker, _scale_cube_pc
 / _mn) with the same return conventions.  Shared-memory ordering: plain stores and loads of CPython on x86-64 (total
 store order): theta before the request counter, logL before the acknowledgement.
@@ -33,7 +39,10 @@ from multiprocessing import shared_memory
 import numpy as np
 
 _MAGIC = 0x4D43414C46425231          # "MCALFBR1"
+_MAGIC_RESIDENT = 0x4D43414C46425232  # "MCALFBR2": mailboxes polled by resident workgroups
 _HDR = 8                             # uint64 words: magic, ndim, slots, startind, stop, served batches, served thetas, reserved
+_BOX = 576                           # bytes of a mailbox (MCALF_MAILBOX_BYTES): u32 req, quit, ack, state; f64 result; 5 reserved; f64 row[64]
+_PENDING = 0x7FF8C0DEC0DE0001        # MCALF_RESULT_PENDING
 
 
 def _layout(ndim: int, slots: int):
@@ -46,6 +55,29 @@ def _layout(ndim: int, slots: int):
         off[name] = pos
         pos += n * 8
     return off, pos
+
+
+def _layout_resident(ndim: int, slots: int):
+    off = {"hdr": 0}
+    pos = _HDR * 8
+    for name, n in (("lo", ndim * 8), ("hi", ndim * 8), ("box", slots * _BOX)):
+        pos = (pos + 63) & ~63
+        off[name] = pos
+        pos += n
+    return off, (pos + 4095) & ~4095
+
+
+class _ResidentViews:
+    def __init__(self, buf, ndim, slots):
+        off, _ = _layout_resident(ndim, slots)
+        self.off = off
+        self.hdr = np.ndarray((_HDR,), dtype=np.uint64, buffer=buf, offset=off["hdr"])
+        self.lo = np.ndarray((ndim,), dtype=np.float64, buffer=buf, offset=off["lo"])
+        self.hi = np.ndarray((ndim,), dtype=np.float64, buffer=buf, offset=off["hi"])
+        self.words = np.ndarray((slots, _BOX // 4), dtype=np.uint32, buffer=buf, offset=off["box"])     # [:, 0] req, 1 quit, 2 ack, 3 state
+        self.res_bits = np.ndarray((slots, _BOX // 8), dtype=np.uint64, buffer=buf, offset=off["box"])[:, 2]
+        self.res = np.ndarray((slots, _BOX // 8), dtype=np.float64, buffer=buf, offset=off["box"])[:, 2]
+        self.rows = np.ndarray((slots, _BOX // 8), dtype=np.float64, buffer=buf, offset=off["box"])[:, 8:]
 
 
 class _Views:
@@ -65,26 +97,34 @@ class LikelihoodBroker:
     `loglike_batch(P) -> logL` -- or a sequence of such evaluators of the SAME problem, one launch in flight on each
     (native loop only); the device contexts live here and nowhere else."""
 
-    def __init__(self, fit, name: str, slots: int = 64):
+    def __init__(self, fit, name: str, slots: int = 64, resident_us: int = 0):
+        self.resident_us = int(resident_us)
         self.fits = list(fit) if isinstance(fit, (list, tuple)) else [fit]
         fit = self.fits[0]
         if any(int(f.ndim) != int(fit.ndim) for f in self.fits):
             raise ValueError("the broker's evaluators must describe the same problem")
         self.fit, self.name, self.slots = fit, name, int(slots)
         self.ndim = int(fit.ndim)
-        _, size = _layout(self.ndim, self.slots)
+        if self.resident_us > 0:
+            if not self.native or self.ndim > 64:
+                raise ValueError("resident evaluators need a library context and at most 64 parameters")
+            _, size = _layout_resident(self.ndim, self.slots)
+        else:
+            _, size = _layout(self.ndim, self.slots)
         self.shm = shared_memory.SharedMemory(name=name, create=True, size=size)
         self.shm.buf[:size] = bytes(size)
-        self.v = _Views(self.shm.buf, self.ndim, self.slots)
+        self.v = (_ResidentViews if self.resident_us > 0 else _Views)(self.shm.buf, self.ndim, self.slots)
         # min / max of every bounds entry, as _scale_cube_pc takes them (hires_fitter.py:205-206)
         self.v.lo[:] = [np.min(b) for b in fit.bounds]
         self.v.hi[:] = [np.max(b) for b in fit.bounds]
         self.v.hdr[1], self.v.hdr[2], self.v.hdr[3] = self.ndim, self.slots, int(fit.startind)
-        self.v.hdr[0] = _MAGIC                                  # last: a client that sees the magic sees a complete header
+        self.v.hdr[0] = _MAGIC_RESIDENT if self.resident_us > 0 else _MAGIC   # last: a client that sees the magic sees a complete header
         self._batch = np.empty((self.slots, self.ndim))
 
     def poll(self) -> int:
         """Serve every request that is open right now as ONE batch; the number of thetas served."""
+        if self.resident_us > 0:
+            raise RuntimeError("a broker with resident evaluators is served by serve() / serve_native() only")
         v = self.v
         req = v.req.copy()                                      # (a request that arrives after this copy waits one round)
         open_ = np.nonzero(req != v.ack)[0]
@@ -108,8 +148,14 @@ class LikelihoodBroker:
     def serve_native(self, idle_sleep_after: float = 0.05, max_seconds: float = 0.0) -> None:
         """The loop inside the library (mcalf_broker_serve): returns when the stop flag is raised, or after `max_seconds`."""
         from . import _lib
-        off, _ = _layout(self.ndim, self.slots)
         base = C.addressof(C.c_char.from_buffer(self.shm.buf))
+        if self.resident_us > 0:
+            off = self.v.off
+            rc = self.fit._lib.mcalf_broker_serve_resident(self.fit._ctx, base + off["box"], self.slots, base + off["hdr"] + 4 * 8,
+                                                           self.resident_us, base + off["hdr"] + 5 * 8, float(max_seconds))
+            _lib.check(rc, self.fit._ctx)
+            return
+        off, _ = _layout(self.ndim, self.slots)
         d = _lib.mcalf_broker_t(slots=self.slots, ndim=self.ndim, req=base + off["req"], ack=base + off["ack"], counter_stride=8,
                                 theta=base + off["theta"], theta_stride=self.ndim, logl=base + off["logl"], logl_stride=8,
                                 stop=base + off["hdr"] + 4 * 8, stats=base + off["hdr"] + 5 * 8, idle_sleep_after_s=idle_sleep_after)
@@ -122,7 +168,7 @@ class LikelihoodBroker:
         coming; after `idle_sleep_after` seconds without one it yields the core between polls.  `native` (default: when
         every evaluator is a library context and no `stop_when` is given) runs the loop inside the library."""
         if native is None:
-            native = self.native and stop_when is None
+            native = self.resident_us > 0 or (self.native and stop_when is None)
         if native:
             return self.serve_native(idle_sleep_after)
         last = time.perf_counter()
@@ -136,6 +182,8 @@ class LikelihoodBroker:
 
     @property
     def stats(self):
+        if self.resident_us > 0:                                # (nobody counts on a call's path: the acknowledged request numbers do)
+            return {"batches": int(self.v.hdr[5]), "thetas": int(self.v.words[:, 2].astype(np.int64).sum())}
         return {"batches": int(self.v.hdr[5]), "thetas": int(self.v.hdr[6])}
 
     def stop(self):
@@ -173,7 +221,7 @@ class BrokerClient:
                 except Exception:  # noqa: BLE001 - private API; the worst case is the warning at exit
                     pass
                 hdr = np.ndarray((_HDR,), dtype=np.uint64, buffer=self.shm.buf)
-                if hdr[0] == _MAGIC:
+                if hdr[0] in (_MAGIC, _MAGIC_RESIDENT):
                     break
                 self.shm.close()
             except FileNotFoundError:
@@ -185,8 +233,16 @@ class BrokerClient:
         if not (0 <= slot < self.slots):
             raise ValueError(f"slot {slot} outside the broker's {self.slots} slots")
         self.slot = int(slot)
-        self.v = _Views(self.shm.buf, self.ndim, self.slots)
-        self._row = self.v.theta[self.slot]
+        self.resident = int(hdr[0]) == _MAGIC_RESIDENT
+        if self.resident:
+            self.v = _ResidentViews(self.shm.buf, self.ndim, self.slots)
+            self._row = self.v.rows[self.slot][: self.ndim]
+            self._req = self.v.words[self.slot]                  # [0] is the request number
+            self._bits = self.v.res_bits[self.slot: self.slot + 1]
+            self._pending = np.uint64(_PENDING)
+        else:
+            self.v = _Views(self.shm.buf, self.ndim, self.slots)
+            self._row = self.v.theta[self.slot]
         self.bounds = np.stack([self.v.lo, self.v.hi], axis=1).copy()
         self._ptp = self.bounds[:, 1] - self.bounds[:, 0]
 
@@ -194,6 +250,18 @@ class BrokerClient:
     def lnlhood_worker(self, p):
         int(p[self.startind])                              # raises where the reference's int() does (:428)
         v, s = self.v, self.slot
+        if self.resident:
+            # the rank's mailbox, polled by its workgroup on the GPU: result <- pending, row, then the request number
+            bits, pend = self._bits, self._pending
+            bits[0] = pend
+            self._row[:] = p                                # (raises for a wrong length)
+            self._req[0] += np.uint32(1)
+            n = 0
+            while bits[0] == pend:
+                n += 1
+                if not (n & 0xFFFF) and v.hdr[4]:
+                    raise RuntimeError("the likelihood broker has stopped")
+            return float(v.res[s])
         self._row[:] = p                                    # (raises for a wrong length)
         seq = v.req[s] + np.uint64(1)
         v.req[s] = seq                                      # theta first, then the request

@@ -1389,26 +1389,45 @@ struct alignas(64) ResidentBox {
     double pad[5];
     double row[kResRowMax];      // host: the parameter row
 };
+// Words the workgroups of ONE resident launch share (device memory, zeroed by the host before the launch): the time of
+// the launch's last answered request, and the word that tells everybody to leave.  A launch may hold one workgroup (a
+// context's own evaluator) or one per mailbox (the broker: workgroup k serves mailbox k); its workgroups leave TOGETHER --
+// when workgroup 0 finds that none of them has answered anything for `idle_ticks`, or when a mailbox says `quit` -- so
+// that one launch on one stream is all there ever is (hardware queues are few: a launch per mailbox, each on its own
+// stream, had the resident kernels of one queue wait for each other's idle limits).
+struct ResidentShared {
+    unsigned long long last;     // s_memrealtime of the last answer of any workgroup of the launch
+    unsigned int leave;          // non-zero: everybody leaves (after a last look at their mailboxes)
+    unsigned int pad;
+};
 template <bool kZeroPad, bool kSelfHalo>
-__global__ __launch_bounds__(kBlock, 2) void mcalf_resident_kernel(const KArgs a, ResidentBox* box, unsigned first,
+__global__ __launch_bounds__(kBlock, 2) void mcalf_resident_kernel(const KArgs a, ResidentBox* boxes, ResidentShared* shared,
                                                                            long long idle_ticks, int row_offset_doubles) {
     extern __shared__ __align__(16) double smem[];
     double* sRow = smem + row_offset_doubles;            // behind everything the item uses
     unsigned* sCtl = reinterpret_cast<unsigned*>(sRow + kResRowMax);
     const int tid = threadIdx.x;
-    unsigned seen = first - 1u;
+    ResidentBox* box = boxes + blockIdx.x;
+    const unsigned long long t_launch = __builtin_amdgcn_s_memrealtime();
+    // the number of the last request this mailbox has had answered: what comes next is new
+    unsigned seen = __hip_atomic_load(&box->ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     while (true) {
         if (tid == 0) {
             unsigned r;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             while (true) {
                 // (`req` and `quit` share eight bytes: ONE PCIe read per look)
                 const unsigned long long both = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&box->req), __ATOMIC_RELAXED,
                                                                    __HIP_MEMORY_SCOPE_SYSTEM);
                 r = (unsigned)both;
                 if (r != seen) break;
-                const bool told = (unsigned)(both >> 32) != 0u;
-                if (told || (long long)(__builtin_amdgcn_s_memrealtime() - t0) > idle_ticks) {
+                bool leave = (unsigned)(both >> 32) != 0u || __hip_atomic_load(&shared->leave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                if (!leave && blockIdx.x == 0) {         // workgroup 0 keeps the launch's clock
+                    const unsigned long long last = __hip_atomic_load(&shared->last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long since = last > t_launch ? last : t_launch;
+                    if ((long long)(__builtin_amdgcn_s_memrealtime() - since) > idle_ticks) leave = true;
+                }
+                if (leave) {
+                    __hip_atomic_store(&shared->leave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&box->state, kResLeaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     stream_stores_done();                // (a read does not pass the posted write: the host has "leaving" before this look)
                     r = __hip_atomic_load(&box->req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1437,12 +1456,15 @@ __global__ __launch_bounds__(kBlock, 2) void mcalf_resident_kernel(const KArgs a
         ArgSeg* kp = (ArgSeg*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
         KArgs b = *(const KArgs*)kp;
-        b.P = sRow;
-        b.out = &box->result;
+        // (the item of workgroup k is "live point k": its row is the one in LDS, its result slot the mailbox's)
+        const int rowlen = b.ndim;
+        b.P = sRow - (size_t)blockIdx.x * rowlen;
+        b.out = &box->result - blockIdx.x;
         fused_items<kZeroPad, kSelfHalo, 4, true, false>(b, smem);
         if (tid == 0) {                                  // (thread 0 stored the result itself)
             stream_stores_done();
             __hip_atomic_store(&box->ack, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_fetch_max(&shared->last, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         seen = r;
         __syncthreads();
@@ -1533,6 +1555,7 @@ struct mcalf_ctx {
     // believes about the kernel, the next request number
     ResidentBox* h_box = nullptr;       // page-locked, coherent, device-mapped
     ResidentBox* d_box = nullptr;
+    ResidentShared* d_res_shared = nullptr;   // device words of the evaluator's launch (idle clock, leave flag)
     hipStream_t res_stream = nullptr;
     int resident_us = 0;                // idle limit in microseconds; 0 = no resident kernel
     bool res_alive = false;
@@ -1689,6 +1712,7 @@ extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     resident_stop(ctx);
     if (ctx->res_stream) (void)hipStreamDestroy(ctx->res_stream);
     if (ctx->h_box) (void)hipHostFree((void*)ctx->h_box);
+    if (ctx->d_res_shared) (void)hipFree(ctx->d_res_shared);
     void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_err, ctx->d_tabs, ctx->d_lines, ctx->d_wtab, ctx->d_segok,
                     ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds, ctx->d_prior, ctx->d_recs, ctx->d_taps, ctx->d_hdr,
                     ctx->d_queue, ctx->d_order, ctx->d_sws};
@@ -2682,6 +2706,7 @@ static int resident_call(mcalf_ctx* ctx, const double* row, int rowlen, double* 
         std::memset((void*)ctx->h_box, 0, sizeof(ResidentBox));
         HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->d_box, (void*)ctx->h_box, 0));
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->res_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_res_shared, sizeof(ResidentShared)));
         const void* k = resident_kernel_ptr(ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX, ctx->selfhalo != 0);
         HIP_TRY(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsBudget + 1024)));
     }
@@ -2701,11 +2726,12 @@ static int resident_call(mcalf_ctx* ctx, const double* row, int rowlen, double* 
         __atomic_store_n(&box->quit, 0u, __ATOMIC_RELAXED);
         __atomic_store_n(&box->req, seq, __ATOMIC_RELEASE);
         ResidentBox* dbox = ctx->d_box;
-        unsigned first = seq;
+        ResidentShared* dsh = ctx->d_res_shared;
         long long idle = (long long)ctx->resident_us * 100;                  // ticks of the 100 MHz clock
         int row_off = (int)((ctx->lds_bytes_inline / sizeof(double) + 1) & ~(size_t)1);
-        void* kargs[] = {(void*)&a, (void*)&dbox, (void*)&first, (void*)&idle, (void*)&row_off};
+        void* kargs[] = {(void*)&a, (void*)&dbox, (void*)&dsh, (void*)&idle, (void*)&row_off};
         const size_t lds = (size_t)row_off * sizeof(double) + kResRowMax * sizeof(double) + 16;
+        HIP_TRY(ctx, hipMemsetAsync(dsh, 0, sizeof(ResidentShared), ctx->res_stream));
         HIP_TRY(ctx, hipLaunchKernel(resident_kernel_ptr(ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX, ctx->selfhalo != 0), dim3(1), dim3(kBlock),
                                      kargs, lds, ctx->res_stream));
         ctx->res_alive = true;
@@ -2955,6 +2981,76 @@ extern "C" int mcalf_broker_serve(mcalf_ctx* const* ctxs, int32_t nctx, const mc
         }
         if (max_seconds > 0 && (t - t_begin) * 1e-6 > max_seconds) stopping = true;
     }
+}
+
+// The broker with resident evaluators: one workgroup per solver rank, polling the rank's mailbox in the shared block.
+// The serving thread is OFF the path of a call: it only starts the launch of those workgroups when a request finds none.
+extern "C" int mcalf_broker_serve_resident(mcalf_ctx* ctx, void* boxes, int32_t slots, volatile uint64_t* stop, int32_t idle_us,
+                                           uint64_t* stats, double max_seconds) {
+    static_assert(sizeof(ResidentBox) == MCALF_MAILBOX_BYTES, "mailbox layout of include/mcalf_hip.h");
+    static_assert(kResultPending == MCALF_RESULT_PENDING, "pending pattern of include/mcalf_hip.h");
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    if (!boxes || !stop || slots < 1 || slots > 256 || idle_us < 1 || idle_us > 1000000 || (reinterpret_cast<uintptr_t>(boxes) & 63))
+        return set_err(ctx, MCALF_ERR_INVALID, "resident broker: 1 .. 256 mailboxes at a 64-byte aligned address, idle limit 1 .. 1000000 us");
+    if (ctx->ntiles != 1 || ctx->ndim > kResRowMax)
+        return set_err(ctx, MCALF_ERR_RANGE, "resident broker: the spectrum must fit one pixel tile and a row 64 parameters "
+                       "(%d tiles, %d parameters): use mcalf_broker_serve", ctx->ntiles, ctx->ndim);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ResidentBox* hb = static_cast<ResidentBox*>(boxes);
+    const size_t bytes = (size_t)slots * sizeof(ResidentBox);
+    HIP_TRY(ctx, hipHostRegister(boxes, bytes, hipHostRegisterMapped));
+    ResidentBox* db = nullptr;
+    ResidentShared* dsh = nullptr;
+    hipStream_t st = nullptr;
+    int rc = MCALF_OK;
+    auto fail = [&](hipError_t e, const char* what) { rc = set_err(ctx, MCALF_ERR_HIP, "resident broker: %s failed: %s", what, hipGetErrorString(e)); };
+    hipError_t he = hipHostGetDevicePointer((void**)&db, boxes, 0);
+    if (he != hipSuccess) fail(he, "hipHostGetDevicePointer");
+    const void* kern = resident_kernel_ptr(ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX, ctx->selfhalo != 0);
+    if (rc == MCALF_OK && (he = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsBudget + 1024))) != hipSuccess)
+        fail(he, "hipFuncSetAttribute");
+    if (rc == MCALF_OK && (he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) fail(he, "hipStreamCreate");
+    if (rc == MCALF_OK && (he = hipMalloc((void**)&dsh, sizeof(ResidentShared))) != hipSuccess) fail(he, "hipMalloc");
+    bool launched = false;
+    const double t_begin = now_us();
+    while (rc == MCALF_OK) {
+        if (__atomic_load_n(const_cast<uint64_t*>(stop), __ATOMIC_ACQUIRE) != 0) break;
+        bool open = false;
+        for (int s = 0; s < slots && !open; ++s)
+            open = __atomic_load_n(&hb[s].req, __ATOMIC_ACQUIRE) != __atomic_load_n(&hb[s].ack, __ATOMIC_ACQUIRE);
+        if (open) {
+            // ONE launch serves every mailbox (workgroup k polls mailbox k) and its workgroups leave together: while it is
+            // there, an open request is being answered -- or its workgroup has just left with the others and the launch is
+            // about to end.  Only when the launch has ended is another one started.
+            const hipError_t q = launched ? hipStreamQuery(st) : hipSuccess;
+            if (q == hipSuccess) {
+                KArgs a = make_kargs(ctx, kModeLogL, nullptr, 0, 1, 0, 0, 0, nullptr, nullptr, false, nullptr);
+                a.persist = 0; a.order = nullptr;
+                for (int s = 0; s < slots; ++s) __atomic_store_n(&hb[s].state, kResRunning, __ATOMIC_RELEASE);
+                long long idle = (long long)idle_us * 100;
+                int row_off = (int)((ctx->lds_bytes_inline / sizeof(double) + 1) & ~(size_t)1);
+                void* kargs[] = {(void*)&a, (void*)&db, (void*)&dsh, (void*)&idle, (void*)&row_off};
+                const size_t lds = (size_t)row_off * sizeof(double) + kResRowMax * sizeof(double) + 16;
+                if ((he = hipMemsetAsync(dsh, 0, sizeof(ResidentShared), st)) != hipSuccess) { fail(he, "hipMemsetAsync"); break; }
+                if ((he = hipLaunchKernel(kern, dim3((unsigned)slots), dim3(kBlock), kargs, lds, st)) != hipSuccess) { fail(he, "hipLaunchKernel"); break; }
+                launched = true;
+                if (stats) stats[0] += 1;
+            } else if (q != hipErrorNotReady) {
+                fail(q, "the resident launch");
+                break;
+            }
+        }
+        struct timespec ts = {0, 20000};                  // (the serving thread is not on a call's path: it only restarts the launch)
+        nanosleep(&ts, nullptr);
+        if (max_seconds > 0 && (now_us() - t_begin) * 1e-6 > max_seconds) break;
+    }
+    // everybody out: tell the workgroups, wait for them (bounded by the idle limit anyway), give the block back
+    for (int s = 0; s < slots; ++s) __atomic_store_n(&hb[s].quit, 1u, __ATOMIC_RELEASE);
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (int s = 0; s < slots; ++s) __atomic_store_n(&hb[s].quit, 0u, __ATOMIC_RELEASE);
+    if (dsh) (void)hipFree(dsh);
+    (void)hipHostUnregister(boxes);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------------

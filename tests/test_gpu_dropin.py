@@ -134,3 +134,44 @@ def test_small_calls_read_their_completion_off_the_results(cfg, monkeypatch):
     assert np.array_equal(got["1"][0], got["1"][1][:12], equal_nan=True)
     for k in range(2):
         assert np.array_equal(got["1"][k], got["0"][k], equal_nan=True)
+
+
+def test_ranks_behind_the_broker_with_resident_workgroups_get_the_same_bits():
+    """mcalf_broker_serve_resident: every rank's mailbox in the shared block is polled by a workgroup that stays on the GPU; the
+    serving thread only (re)starts the launch of those workgroups (at start-up and after they have all left -- the idle limit
+    here is short enough for both to happen).  Ranks hold no device context; same client class; bits of an own context."""
+    import multiprocessing as mp
+    import threading
+    from mcalf_amd import broker
+    kw, _, seed = workloads.config("B", oracle_synth)
+    P = workloads.draw_P(kw, 30, np.random.default_rng(seed + 8))
+    name = f"mcalf_gputest_resident_{os.getpid()}"
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        want = [fit.lnlhood_pc(p)[0] for p in P]
+        with broker.LikelihoodBroker(fit, name, slots=4, resident_us=150) as b:
+            server = threading.Thread(target=b.serve_native, kwargs={"max_seconds": 240.0})
+            server.start()
+            ctx = mp.get_context("spawn")
+            q = ctx.Queue()
+            procs = [ctx.Process(target=_broker_rank, args=(name, r, P[r::3], q)) for r in range(3)]
+            for p in procs:
+                p.start()
+            got = {}
+            t0 = time.time()
+            while len(got) < 3 and time.time() - t0 < 240 and server.is_alive():
+                try:
+                    r, vals = q.get(timeout=0.2)
+                    got[r] = vals
+                except Exception:  # noqa: BLE001 - queue.Empty
+                    pass
+            stats = b.stats
+            b.stop()
+            server.join(timeout=60)
+            for p in procs:
+                p.join(timeout=30)
+            assert not server.is_alive() and len(got) == 3
+            for r in range(3):
+                assert got[r] == want[r::3]
+            assert stats["thetas"] == 30 and stats["batches"] >= 1      # (launches of the resident grid: it leaves when every rank is quiet)
+        # the context is as good as before
+        assert fit.lnlhood_pc(P[0])[0] == want[0]

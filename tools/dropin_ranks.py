@@ -113,7 +113,7 @@ def worker_threads(cfg, rank, nranks, calls, work, nthreads):
         json.dump(res, fh)
 
 
-def broker_server(cfg, name, slots, work, lanes=0):
+def broker_server(cfg, name, slots, work, lanes=0, resident_us=0):
     """The one process with device contexts: serves the clients' thetas in batches (mc-alf_amd/broker.py).  lanes = 0: the
     Python loop, one context; lanes >= 1: the loop inside the library (mcalf_broker_serve) over that many contexts."""
     import threading
@@ -124,9 +124,9 @@ def broker_server(cfg, name, slots, work, lanes=0):
     kw, _, _ = workloads.config(cfg, oracle_synth)
     fits = [mcalf_amd.als_fitter(None, **kw) for _ in range(max(lanes, 1))]
     stop_file = os.path.join(work, "stop")
-    with broker.LikelihoodBroker(fits, name, slots=slots) as b:
+    with broker.LikelihoodBroker(fits if not resident_us else fits[0], name, slots=slots, resident_us=resident_us) as b:
         open(os.path.join(work, "server_ready"), "w").close()
-        if lanes == 0:
+        if lanes == 0 and not resident_us:
             b.serve(stop_when=lambda: os.path.exists(stop_file), native=False)
         else:
             def watch():
@@ -176,12 +176,12 @@ def broker_client(cfg, rank, nranks, calls, work, name):
         json.dump(res, fh)
 
 
-def run_broker(cfg, nranks, calls, lanes=0):
+def run_broker(cfg, nranks, calls, lanes=0, resident_us=0):
     work = tempfile.mkdtemp(prefix="mcalf_broker_")
     name = "mcalf_dropin_%d" % os.getpid()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     me = os.path.abspath(__file__)
-    server = subprocess.Popen([sys.executable, me, "--broker-server", cfg, name, str(max(nranks, 1)), work, str(lanes)], env=env)
+    server = subprocess.Popen([sys.executable, me, "--broker-server", cfg, name, str(max(nranks, 1)), work, str(lanes), str(resident_us)], env=env)
     t0 = time.time()
     while not os.path.exists(os.path.join(work, "server_ready")):
         if time.time() - t0 > 300 or server.poll() is not None:
@@ -206,7 +206,8 @@ def run_broker(cfg, nranks, calls, lanes=0):
     st = json.load(open(os.path.join(work, "server.json")))
     same = all(r["shared_logL"] == res[0]["shared_logL"] for r in res)
     return {"ranks": nranks, "processes": nranks, "threads_per_process": 1, "broker": True, "calls_per_rank": calls,
-            "server_loop": "python, 1 context" if lanes == 0 else "library (mcalf_broker_serve), %d context(s)" % lanes,
+            "server_loop": ("resident workgroups (mcalf_broker_serve_resident), idle limit %d us" % resident_us) if resident_us else
+                           ("python, 1 context" if lanes == 0 else "library (mcalf_broker_serve), %d context(s)" % lanes),
             "thetas_per_launch": st["thetas"] / max(st["batches"], 1),
             "aggregate_logL_per_s": sum(r["calls"] / r["wall_s"] for r in res),
             "us_per_call_mean": sum(r["us_mean"] for r in res) / nranks,
@@ -245,7 +246,8 @@ def run(cfg, nranks, calls, nthreads=1):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--broker-server":
-        broker_server(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5], int(sys.argv[6]) if len(sys.argv) > 6 else 0)
+        broker_server(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5], int(sys.argv[6]) if len(sys.argv) > 6 else 0,
+                      int(sys.argv[7]) if len(sys.argv) > 7 else 0)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "--broker-client":
         broker_client(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], sys.argv[7])
@@ -266,6 +268,10 @@ def main():
     rows = []
     for spec in args.ranks.split(","):
         if spec.startswith("b"):                            # bR: R ranks WITHOUT device contexts behind one likelihood broker
+            if "r" in spec:                                 # bRrU: resident workgroups, idle limit U microseconds
+                nr, _, us = spec[1:].partition("r")
+                rows.append(run_broker(args.config, int(nr), args.calls, 0, int(us)))
+                continue
             nr, _, ln = spec[1:].partition("l")             # (Python loop); bRlL: the library's loop over L contexts
             rows.append(run_broker(args.config, int(nr), args.calls, int(ln) if ln else 0))
             continue
