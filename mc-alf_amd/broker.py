@@ -190,6 +190,8 @@ class LikelihoodBroker:
         self.v.hdr[4] = 1
 
     def close(self):
+        if self.v is not None:
+            self.v.hdr[4] = 1                                   # a rank that is still waiting gets an exception, not a hang
         self.v = None
         try:
             self.shm.close()
