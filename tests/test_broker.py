@@ -82,3 +82,59 @@ def test_broker_client_errors():
         with pytest.raises(RuntimeError, match="stopped"):
             cl.lnlhood_pc(np.ones(5))
         cl.close()
+
+
+def test_clients_of_a_block_with_mailboxes_speak_the_resident_protocol():
+    """The ranks' side of the broker with resident workgroups, without a GPU: a thread plays the workgroups (poll `req`, read
+    the row, store the result, then `ack`) on a block laid out as LikelihoodBroker(resident_us=...) lays it out; the same
+    BrokerClient recognises the block's kind and speaks the mailbox protocol -- result <- pending pattern, row, req + 1."""
+    import threading
+    from multiprocessing import shared_memory
+    name = f"mcalf_test_res_{os.getpid()}"
+    ndim, slots = FakeFit.ndim, 3
+    _, size = broker._layout_resident(ndim, slots)
+    shm = shared_memory.SharedMemory(name=name, create=True, size=size)
+    shm.buf[:size] = bytes(size)
+    v = broker._ResidentViews(shm.buf, ndim, slots)
+    v.lo[:] = [np.min(b) for b in FakeFit.bounds]
+    v.hi[:] = [np.max(b) for b in FakeFit.bounds]
+    v.hdr[1], v.hdr[2], v.hdr[3] = ndim, slots, FakeFit.startind
+    v.hdr[0] = broker._MAGIC_RESIDENT
+    served = [0]
+
+    def workgroups():
+        while not v.hdr[4]:
+            for s in range(slots):
+                req = v.words[s, 0]
+                if req != v.words[s, 2]:
+                    assert v.res_bits[s] == np.uint64(broker._PENDING)     # the rank filled the slot before it asked
+                    row = v.rows[s][:ndim].copy()
+                    v.res[s] = -0.5 * (row ** 2).sum() + row[0]
+                    v.words[s, 2] = req
+                    served[0] += 1
+            time.sleep(0.0002)
+
+    th = threading.Thread(target=workgroups)
+    th.start()
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_client, args=(name, s, 15, q)) for s in range(slots)]
+        for p in procs:
+            p.start()
+        done = [q.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(timeout=30)
+        assert sorted(d[0] for d in done) == list(range(slots)) and all(d[1] for d in done)
+        assert served[0] == slots * 15 * 3
+        lo, hi = np.array(v.lo), np.array(v.hi)
+        for _, _, thv, cube in done:
+            want = np.array(cube) * (hi - lo) + lo
+            want[1] = int(want[1])
+            assert thv == want.tolist()
+    finally:
+        v.hdr[4] = 1
+        th.join(timeout=10)
+        del v
+        shm.close()
+        shm.unlink()
