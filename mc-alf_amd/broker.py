@@ -92,6 +92,19 @@ class _Views:
         self.theta = np.ndarray((slots, ndim), dtype=np.float64, buffer=buf, offset=off["theta"])
 
 
+def _attach(name):
+    """Attach to an existing block WITHOUT telling the process's resource tracker: Python < 3.13 registers an attached block
+    as if this process had created it, and the tracker then unlinks it when the rank exits -- under the other ranks' feet (the
+    block is the server's).  (Un-registering afterwards is no way out either: ranks spawned by the server share ITS tracker.)"""
+    from multiprocessing import resource_tracker
+    keep = resource_tracker.register
+    resource_tracker.register = lambda *a, **k: None
+    try:
+        return shared_memory.SharedMemory(name=name)
+    finally:
+        resource_tracker.register = keep
+
+
 class LikelihoodBroker:
     """The serving side.  `fit` is anything with `ndim`, `startind`, `bounds` (as `als_fitter` holds them) and
     `loglike_batch(P) -> logL` -- or a sequence of such evaluators of the SAME problem, one launch in flight on each
@@ -214,14 +227,7 @@ class BrokerClient:
         t0 = time.time()
         while True:
             try:
-                self.shm = shared_memory.SharedMemory(name=name)
-                # (Python < 3.13 registers an ATTACHED block with the process's resource tracker as if it had created it,
-                # and the tracker unlinks it when this rank exits -- under the other ranks' feet: the block is the server's)
-                try:
-                    from multiprocessing import resource_tracker
-                    resource_tracker.unregister(self.shm._name, "shared_memory")
-                except Exception:  # noqa: BLE001 - private API; the worst case is the warning at exit
-                    pass
+                self.shm = _attach(name)
                 hdr = np.ndarray((_HDR,), dtype=np.uint64, buffer=self.shm.buf)
                 if hdr[0] in (_MAGIC, _MAGIC_RESIDENT):
                     break
