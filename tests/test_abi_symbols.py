@@ -104,6 +104,8 @@ def test_null_arguments_do_not_crash():
     assert lib.mcalf_loglike_batch(None, None, 4, None) == -1
     assert lib.mcalf_reserve(None, 4) == -1
     assert lib.mcalf_broker_serve(None, 0, None, 0.0) == -1
+    assert lib.mcalf_broker_serve_resident(None, None, 0, None, 0, None, 0.0) == -1
+    assert lib.mcalf_set_resident(None, 100) == -1
     one = (C.c_void_p * 1)(None)
     assert lib.mcalf_broker_serve(one, 1, None, 0.0) == -1
     assert lib.mcalf_voigt_hjerting(None, None, -1, None, -1) == -1
