@@ -186,6 +186,27 @@ int mcalf_broker_serve(mcalf_ctx* const* ctxs, int32_t nctx, const mcalf_broker_
 int mcalf_broker_serve_resident(mcalf_ctx* ctx, void* boxes, int32_t slots, volatile uint64_t* stop, int32_t idle_us,
                                 uint64_t* stats, double max_seconds);
 
+/* A rank's side of the mailbox protocol, for solvers written in C / C++ / Fortran (header-only; the Python ranks do the same in
+ * mc-alf_amd/broker.py): logL of theta[0 .. ndim) through the mailbox at `box`.  Spins until the rank's workgroup has answered;
+ * returns NaN when *stop (may be NULL) becomes non-zero first. */
+#if defined(__GNUC__) || defined(__clang__)
+static inline double mcalf_mailbox_call(void* box, const double* theta, int32_t ndim, const volatile uint64_t* stop) {
+    volatile uint32_t* words = (volatile uint32_t*)box;            /* req, quit, ack, state */
+    volatile uint64_t* result = (volatile uint64_t*)((char*)box + 16);
+    double* row = (double*)((char*)box + 64);
+    union { uint64_t u; double d; } v;
+    int32_t i;
+    uint64_t spins = 0;
+    *result = MCALF_RESULT_PENDING;
+    for (i = 0; i < ndim; ++i) row[i] = theta[i];
+    __atomic_store_n(&words[0], words[0] + 1u, __ATOMIC_RELEASE);  /* the request number, last */
+    while ((v.u = __atomic_load_n(result, __ATOMIC_ACQUIRE)) == MCALF_RESULT_PENDING) {
+        if (stop && (++spins & 0xFFFFu) == 0 && *stop) { v.u = 0x7FF8000000000000ull; break; }
+    }
+    return v.d;
+}
+#endif
+
 /* Row blocks a batch is issued in (0 = automatic [default], n <= 8 = exactly n).  Automatic means ONE block
  * for the *_device entries (the persistent fused kernel leaves no launch tail worth filling; measured) and, for
  * the host-pointer entries with large batches, ONE streaming launch (MCALF_PATH_HOST_STREAM: spectra that fit one pixel

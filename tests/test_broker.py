@@ -138,3 +138,55 @@ def test_clients_of_a_block_with_mailboxes_speak_the_resident_protocol():
         del v
         shm.close()
         shm.unlink()
+
+
+def test_a_rank_written_in_c_speaks_the_mailbox_protocol_of_the_header(tmp_path):
+    """include/mcalf_hip.h's mcalf_mailbox_call(), compiled with gcc into a stand-alone rank, against the block layout of
+    broker.py and a thread that plays the resident workgroups: the C ABI's description of the mailbox and the Python one agree."""
+    import shutil
+    import subprocess
+    import threading
+    from multiprocessing import shared_memory
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "mailbox_client")
+    subprocess.run([gcc, "-O2", "-std=gnu11", "-o", exe, os.path.join(root, "tests", "stubs", "mailbox_client.c"), "-lrt"], check=True)
+    name = f"mcalf_test_c_{os.getpid()}"
+    ndim, slots = 5, 2
+    off, size = broker._layout_resident(ndim, slots)
+    shm = shared_memory.SharedMemory(name=name, create=True, size=size)
+    shm.buf[:size] = bytes(size)
+    v = broker._ResidentViews(shm.buf, ndim, slots)
+    v.hdr[1], v.hdr[2] = ndim, slots
+    v.hdr[0] = broker._MAGIC_RESIDENT
+
+    def workgroups():
+        while not v.hdr[4]:
+            for s in range(slots):
+                req = v.words[s, 0]
+                if req != v.words[s, 2]:
+                    assert v.res_bits[s] == np.uint64(broker._PENDING)
+                    row = v.rows[s][:ndim].copy()
+                    v.res[s] = -0.5 * (row ** 2).sum() + row[0]
+                    v.words[s, 2] = req
+            time.sleep(0.0002)
+
+    th = threading.Thread(target=workgroups)
+    th.start()
+    try:
+        out = subprocess.run([exe, name, str(off["box"] + broker._BOX), str(ndim), "12", "3"], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stderr
+        got = [float(x) for x in out.stdout.split()]
+        want = []
+        for c in range(12):
+            row = np.array([3 + c + k * 0.25 for k in range(ndim)])
+            want.append(float(-0.5 * (row ** 2).sum() + row[0]))
+        assert got == want and int(v.words[1, 2]) == 12 and int(v.words[0, 2]) == 0      # slot 1 was the C rank's
+    finally:
+        v.hdr[4] = 1
+        th.join(timeout=10)
+        del v
+        shm.close()
+        shm.unlink()
