@@ -16,7 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     txt = open(os.path.join(ROOT, "include", "mcalf_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(mcalf_[a-z0-9_]+)\s*\(", txt)))
+    # (header-only helpers -- `static inline` -- are code for the caller's side, not exports of the library)
+    inline = set(re.findall(r"static\s+inline\s+[a-z0-9_ \*]+?\b(mcalf_[a-z0-9_]+)\s*\(", txt))
+    return sorted(set(re.findall(r"\b(mcalf_[a-z0-9_]+)\s*\(", txt)) - inline)
 
 
 def test_header_and_binding_agree():
