@@ -20,6 +20,13 @@
  *   mcalf_loglike_cube_batch <- lnlhood_pc(_scale_cube_pc(cube))      hires_fitter.py:202-209,250-262
  *   mcalf_voigt_hjerting[_nodes] <- scipy.special.wofz(u + i a).real  hires_fitter.py:365
  *                             / voigt_jax.hjert                       voigt_jax.py:121-127
+ *   mcalf_set_resident     <- the solvers' one-theta calling pattern  hires_fitter.py:250-285
+ *                             (lnlhood_pc / _dy / _mn, one call per proposed point)
+ *   mcalf_broker_serve[_resident], mcalf_mailbox_call
+ *                          <- one solver rank per core, each calling  ../cli.py:37-41,110
+ *                             the likelihood serially (PolyChord's MPI workers)
+ *   mcalf_comm_* / mcalf_loglike_gather[v]_device
+ *                          <- data parallelism over live points       ../cli.py:110,274-280
  *
  * Ownership: the context owns all device memory it allocates.  Host pointers passed to
  * any call are borrowed for the duration of that call only.  `*_device` entries take
