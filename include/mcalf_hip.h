@@ -20,6 +20,10 @@
  *   mcalf_loglike_cube_batch <- lnlhood_pc(_scale_cube_pc(cube))      hires_fitter.py:202-209,250-262
  *   mcalf_voigt_hjerting[_nodes] <- scipy.special.wofz(u + i a).real  hires_fitter.py:365
  *                             / voigt_jax.hjert                       voigt_jax.py:121-127
+ *   mcalf_set_cu_mask, mcalf_stream_partition
+ *                          <- the solver hands over host arrays and trusts the float it gets back
+ *                             (hires_fitter.py:250-262,287-294): the host-pointer entries must be right on ANY
+ *                             gfx950 device shape (partition modes, CU masks), not only the one they are fastest on
  *   mcalf_set_resident     <- the solvers' one-theta calling pattern  hires_fitter.py:250-285
  *                             (lnlhood_pc / _dy / _mn, one call per proposed point)
  *   mcalf_broker_serve[_resident], mcalf_mailbox_call
@@ -47,10 +51,12 @@
 extern "C" {
 #endif
 
-#define MCALF_ABI_VERSION 5   /* 2: mcalf_last_launch, gatherv / overlap / join, version string carries the source hash
+#define MCALF_ABI_VERSION 6   /* 2: mcalf_last_launch, gatherv / overlap / join, version string carries the source hash
                                  3: MCALF_PATH_HOST_STREAM, mcalf_launch_info_t grows by stream_setup_wgs / stream_polled
                                  4: mcalf_broker_serve
-                                 5: mcalf_set_resident, mcalf_broker_serve_resident */
+                                 5: mcalf_set_resident, mcalf_broker_serve_resident
+                                 6: mcalf_set_cu_mask, mcalf_stream_partition, mcalf_launch_info_t grows by xcd_mask /
+                                    stream_fallback (the streaming launch is taken only on the device shape it was built for) */
 
 enum {
     MCALF_OK = 0,
@@ -187,30 +193,44 @@ int mcalf_broker_serve(mcalf_ctx* const* ctxs, int32_t nctx, const mcalf_broker_
  * `slots` workgroups alive while requests come (workgroup k polls mailbox k; they leave TOGETHER after idle_us without a
  * request on any mailbox, and the next request starts the launch again -- one launch on one stream, because hardware queues
  * are few); it returns when *stop becomes non-zero (every workgroup has left by then) or after max_seconds (0: never).  Serves spectra of one pixel tile with at
- * most 64 parameters (MCALF_ERR_RANGE otherwise: use mcalf_broker_serve). */
+ * most 64 parameters (MCALF_ERR_RANGE otherwise: use mcalf_broker_serve).
+ * Co-residency: a mailbox is served only while its workgroup is on the chip, and all `slots` workgroups of the launch are
+ * expected to be there at once -- one per compute unit, so `slots` may not exceed the device's CU count (MCALF_ERR_INVALID;
+ * 256 on an unpartitioned MI355X).  While another kernel occupies compute units (a batch call of this process, another
+ * process), workgroups that find no CU leave their mailboxes unpolled until one frees up: such a call waits, it is not lost. */
 #define MCALF_MAILBOX_BYTES 576
 #define MCALF_RESULT_PENDING 0x7FF8C0DEC0DE0001ull
 int mcalf_broker_serve_resident(mcalf_ctx* ctx, void* boxes, int32_t slots, volatile uint64_t* stop, int32_t idle_us,
                                 uint64_t* stats, double max_seconds);
 
 /* A rank's side of the mailbox protocol, for solvers written in C / C++ / Fortran (header-only; the Python ranks do the same in
- * mc-alf_amd/broker.py): logL of theta[0 .. ndim) through the mailbox at `box`.  Spins until the rank's workgroup has answered;
- * returns NaN when *stop (may be NULL) becomes non-zero first. */
+ * mc-alf_amd/broker.py): logL of theta[0 .. ndim) through the mailbox at `box`.  Spins until the rank's workgroup has answered
+ * (the result slot no longer holds the pending pattern, or -- should the answer itself be that pattern -- `ack` equals the
+ * request number); returns the canonical NaN when *stop (may be NULL) becomes non-zero first, or when max_spins (0: no limit)
+ * looks have passed without an answer: a server that has died raises no stop flag, so a caller that cannot watch the server
+ * process should pass a limit (a look is ~10 ns; 3e9 is about half a minute). */
 #if defined(__GNUC__) || defined(__clang__)
-static inline double mcalf_mailbox_call(void* box, const double* theta, int32_t ndim, const volatile uint64_t* stop) {
+static inline double mcalf_mailbox_call_bounded(void* box, const double* theta, int32_t ndim, const volatile uint64_t* stop,
+                                                uint64_t max_spins) {
     volatile uint32_t* words = (volatile uint32_t*)box;            /* req, quit, ack, state */
     volatile uint64_t* result = (volatile uint64_t*)((char*)box + 16);
     double* row = (double*)((char*)box + 64);
     union { uint64_t u; double d; } v;
     int32_t i;
     uint64_t spins = 0;
+    const uint32_t seq = words[0] + 1u;
     *result = MCALF_RESULT_PENDING;
     for (i = 0; i < ndim; ++i) row[i] = theta[i];
-    __atomic_store_n(&words[0], words[0] + 1u, __ATOMIC_RELEASE);  /* the request number, last */
+    __atomic_store_n(&words[0], seq, __ATOMIC_RELEASE);            /* the request number, last */
     while ((v.u = __atomic_load_n(result, __ATOMIC_ACQUIRE)) == MCALF_RESULT_PENDING) {
-        if (stop && (++spins & 0xFFFFu) == 0 && *stop) { v.u = 0x7FF8000000000000ull; break; }
+        if (__atomic_load_n(&words[2], __ATOMIC_ACQUIRE) == seq) { v.u = __atomic_load_n(result, __ATOMIC_ACQUIRE); break; }
+        ++spins;
+        if ((stop && (spins & 0xFFFFu) == 0 && *stop) || (max_spins && spins >= max_spins)) { v.u = 0x7FF8000000000000ull; break; }
     }
     return v.d;
+}
+static inline double mcalf_mailbox_call(void* box, const double* theta, int32_t ndim, const volatile uint64_t* stop) {
+    return mcalf_mailbox_call_bounded(box, theta, ndim, stop, 0);
 }
 #endif
 
@@ -267,8 +287,34 @@ typedef struct {
     int32_t stream_setup_wgs; /* MCALF_PATH_HOST_STREAM: workgroups of the grid dedicated to the set-up while rows were outstanding */
     int32_t stream_polled;  /* MCALF_PATH_HOST_STREAM: 1 = completion seen through the kernel's page-locked word, 0 = stream signal;
                                MCALF_PATH_HOST_ZEROCOPY: 1 = completion read off the results in page-locked memory */
+    int32_t xcd_mask;       /* bit i: the context's probe kernel saw workgroups of its stream on XCD i (hardware XCC_ID).  The
+                               streaming launch deals rows to XCDs 0 .. 7 and is taken only when this is exactly 0xFF */
+    int32_t stream_fallback;/* host-pointer entries, what kept the call from being ONE streaming launch although its size asked
+                               for one: 0 nothing (or not applicable), MCALF_STREAM_FALLBACK_* otherwise -- the row-block
+                               pipeline (MCALF_PATH_HOST_PIPELINED) evaluated the call instead, same bits */
 } mcalf_launch_info_t;
+enum {
+    MCALF_STREAM_FALLBACK_SHAPE = 1,     /* the stream does not reach exactly the eight XCDs of an unpartitioned MI355X
+                                            (DPX / QPX / CPX partition, CU mask): decided before anything was launched */
+    MCALF_STREAM_FALLBACK_TIMEOUT = 2,   /* a wait inside the launch ran out (host thread stalled > MCALF_STREAM_TIMEOUT) */
+    MCALF_STREAM_FALLBACK_STARVED = 3    /* the launch drained, but an XCD that was dealt rows had received no workgroup:
+                                            its rows were never evaluated, the launch's results were discarded */
+};
 int mcalf_last_launch(const mcalf_ctx* ctx, mcalf_launch_info_t* info);
+
+/* Restrict the context's own streams (the host-pointer entries; *_device entries run on the CALLER's stream) to the
+ * compute units of `mask` -- bit i of word i / 32 = CU i in the runtime's numbering (hipExtStreamCreateWithCUMask; on a
+ * multi-XCD device consecutive bits go round the XCDs) -- as an embedding application does to share one GPU between
+ * ranks.  nwords = 0 removes the mask.  The context waits for its streams, re-creates them and probes again which XCDs
+ * they reach: on anything but all eight XCDs of an unpartitioned MI355X large host-pointer batches take the row-block
+ * pipeline instead of the streaming launch (mcalf_launch_info_t.xcd_mask / .stream_fallback say so).  Results never
+ * depend on the mask. */
+int mcalf_set_cu_mask(mcalf_ctx* ctx, const uint32_t* mask, int32_t nwords);
+
+/* How a streaming launch deals the rows of a batch to `nxcd` XCDs (blocks of eight rows, block k -> XCD k % nxcd): for
+ * every row r < nrows, owner[r] = its XCD and local[r] = its index in that XCD's queue.  Pure host arithmetic (no
+ * device needed) -- the same constexpr functions the kernels use; tests check that it is a bijection for every count. */
+int mcalf_stream_partition(int32_t nrows, int32_t nxcd, int32_t* owner, int32_t* local);
 
 /* Measurement aid: between _begin and _end every fused-kernel launch of this context is bracketed by
  * HIP events on the stream it is launched on (at most max_launches of them); _end waits for them and

@@ -85,7 +85,12 @@ class mcalf_launch_info_t(C.Structure):
         ("ordered", C.c_int32),
         ("stream_setup_wgs", C.c_int32),
         ("stream_polled", C.c_int32),
+        ("xcd_mask", C.c_int32),
+        ("stream_fallback", C.c_int32),
     ]
+
+
+MCALF_STREAM_FALLBACK_SHAPE, MCALF_STREAM_FALLBACK_TIMEOUT, MCALF_STREAM_FALLBACK_STARVED = 1, 2, 3
 
 
 class mcalf_broker_t(C.Structure):
@@ -125,6 +130,8 @@ SYMBOLS = {
     "mcalf_loglike_batch_device": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "mcalf_model_batch_device": (C.c_int, [_CTX, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "mcalf_last_launch": (C.c_int, [_CTX, C.POINTER(mcalf_launch_info_t)]),
+    "mcalf_set_cu_mask": (C.c_int, [_CTX, C.POINTER(C.c_uint32), C.c_int32]),
+    "mcalf_stream_partition": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mcalf_profile_begin": (C.c_int, [_CTX, C.c_int32]),
     "mcalf_profile_end": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mcalf_scale_cube_batch": (C.c_int, [_CTX, _PD, _PD, _PD, C.c_int64, C.c_int32, _PD]),

@@ -33,6 +33,7 @@ store order): theta before the request counter, logL before the acknowledgement.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 from multiprocessing import shared_memory
 
@@ -40,7 +41,7 @@ import numpy as np
 
 _MAGIC = 0x4D43414C46425231          # "MCALFBR1"
 _MAGIC_RESIDENT = 0x4D43414C46425232  # "MCALFBR2": mailboxes polled by resident workgroups
-_HDR = 8                             # uint64 words: magic, ndim, slots, startind, stop, served batches, served thetas, reserved
+_HDR = 8                             # uint64 words: magic, ndim, slots, startind, stop, served batches, served thetas, server pid
 _BOX = 576                           # bytes of a mailbox (MCALF_MAILBOX_BYTES): u32 req, quit, ack, state; f64 result; 5 reserved; f64 row[64]
 _PENDING = 0x7FF8C0DEC0DE0001        # MCALF_RESULT_PENDING
 
@@ -105,6 +106,21 @@ def _attach(name):
         resource_tracker.register = keep
 
 
+def _process_alive(pid: int) -> bool:
+    """Whether process `pid` exists and still runs (a zombie -- dead, not yet reaped by its parent -- does not)."""
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except PermissionError:                                 # (another user's process: it exists)
+        return True
+    try:
+        with open(f"/proc/{pid}/stat") as fh:
+            return fh.read().rsplit(")", 1)[1].split()[0] != "Z"
+    except (OSError, IndexError):
+        return True
+
+
 class LikelihoodBroker:
     """The serving side.  `fit` is anything with `ndim`, `startind`, `bounds` (as `als_fitter` holds them) and
     `loglike_batch(P) -> logL` -- or a sequence of such evaluators of the SAME problem, one launch in flight on each
@@ -131,6 +147,7 @@ class LikelihoodBroker:
         self.v.lo[:] = [np.min(b) for b in fit.bounds]
         self.v.hi[:] = [np.max(b) for b in fit.bounds]
         self.v.hdr[1], self.v.hdr[2], self.v.hdr[3] = self.ndim, self.slots, int(fit.startind)
+        self.v.hdr[7] = os.getpid()                             # (the ranks watch this process: a server that dies raises no stop flag)
         self.v.hdr[0] = _MAGIC_RESIDENT if self.resident_us > 0 else _MAGIC   # last: a client that sees the magic sees a complete header
         self._batch = np.empty((self.slots, self.ndim))
 
@@ -162,19 +179,26 @@ class LikelihoodBroker:
         """The loop inside the library (mcalf_broker_serve): returns when the stop flag is raised, or after `max_seconds`."""
         from . import _lib
         base = C.addressof(C.c_char.from_buffer(self.shm.buf))
-        if self.resident_us > 0:
-            off = self.v.off
-            rc = self.fit._lib.mcalf_broker_serve_resident(self.fit._ctx, base + off["box"], self.slots, base + off["hdr"] + 4 * 8,
-                                                           self.resident_us, base + off["hdr"] + 5 * 8, float(max_seconds))
+        ok = False
+        try:
+            if self.resident_us > 0:
+                off = self.v.off
+                rc = self.fit._lib.mcalf_broker_serve_resident(self.fit._ctx, base + off["box"], self.slots, base + off["hdr"] + 4 * 8,
+                                                               self.resident_us, base + off["hdr"] + 5 * 8, float(max_seconds))
+            else:
+                off, _ = _layout(self.ndim, self.slots)
+                d = _lib.mcalf_broker_t(slots=self.slots, ndim=self.ndim, req=base + off["req"], ack=base + off["ack"], counter_stride=8,
+                                        theta=base + off["theta"], theta_stride=self.ndim, logl=base + off["logl"], logl_stride=8,
+                                        stop=base + off["hdr"] + 4 * 8, stats=base + off["hdr"] + 5 * 8, idle_sleep_after_s=idle_sleep_after)
+                ctxs = (C.c_void_p * len(self.fits))(*[f._ctx for f in self.fits])
+                rc = self.fit._lib.mcalf_broker_serve(ctxs, len(self.fits), C.byref(d), float(max_seconds))
             _lib.check(rc, self.fit._ctx)
-            return
-        off, _ = _layout(self.ndim, self.slots)
-        d = _lib.mcalf_broker_t(slots=self.slots, ndim=self.ndim, req=base + off["req"], ack=base + off["ack"], counter_stride=8,
-                                theta=base + off["theta"], theta_stride=self.ndim, logl=base + off["logl"], logl_stride=8,
-                                stop=base + off["hdr"] + 4 * 8, stats=base + off["hdr"] + 5 * 8, idle_sleep_after_s=idle_sleep_after)
-        ctxs = (C.c_void_p * len(self.fits))(*[f._ctx for f in self.fits])
-        rc = self.fit._lib.mcalf_broker_serve(ctxs, len(self.fits), C.byref(d), float(max_seconds))
-        _lib.check(rc, self.fit._ctx)
+            ok = True
+        finally:
+            # a loop that ended with an ERROR serves nobody any more: the ranks that are waiting must get an exception, not
+            # spin for ever (a loop that ended because of max_seconds may be entered again: no flag)
+            if not ok and self.v is not None:
+                self.v.hdr[4] = 1
 
     def serve(self, idle_sleep_after: float = 0.05, stop_when=None, native=None) -> None:
         """Serve until a client (or `stop()`) raises the stop flag, or `stop_when()` says so.  Spins while requests keep
@@ -185,13 +209,19 @@ class LikelihoodBroker:
         if native:
             return self.serve_native(idle_sleep_after)
         last = time.perf_counter()
-        while not self.v.hdr[4]:
-            if self.poll():
-                last = time.perf_counter()
-            elif time.perf_counter() - last > idle_sleep_after:
-                if stop_when is not None and stop_when():
-                    break
-                time.sleep(0.0002)
+        ok = False
+        try:
+            while not self.v.hdr[4]:
+                if self.poll():
+                    last = time.perf_counter()
+                elif time.perf_counter() - last > idle_sleep_after:
+                    if stop_when is not None and stop_when():
+                        break
+                    time.sleep(0.0002)
+            ok = True
+        finally:
+            if not ok and self.v is not None:                   # (the evaluator raised: see serve_native)
+                self.v.hdr[4] = 1
 
     @property
     def stats(self):
@@ -223,7 +253,11 @@ class BrokerClient:
     """A solver rank's side: the likelihood callables of `als_fitter`, served by the broker `name` through slot `slot`
     (one slot per rank; MPI rank numbers do).  Holds no device context."""
 
-    def __init__(self, name: str, slot: int, timeout: float = 60.0):
+    def __init__(self, name: str, slot: int, timeout: float = 60.0, call_timeout: float | None = 120.0):
+        """`timeout`: seconds to wait for the broker's block to appear.  `call_timeout`: seconds a single likelihood call may
+        wait for its answer before it raises (None: for ever); independently of it a call raises as soon as the server
+        PROCESS is gone (its pid is in the header) -- a server that dies raises no stop flag."""
+        self.call_timeout = call_timeout
         t0 = time.time()
         while True:
             try:
@@ -231,6 +265,7 @@ class BrokerClient:
                 hdr = np.ndarray((_HDR,), dtype=np.uint64, buffer=self.shm.buf)
                 if hdr[0] in (_MAGIC, _MAGIC_RESIDENT):
                     break
+                del hdr                                     # (the view exports the buffer: close() would raise BufferError)
                 self.shm.close()
             except FileNotFoundError:
                 pass
@@ -238,6 +273,7 @@ class BrokerClient:
                 raise RuntimeError(f"no likelihood broker named {name!r}")
             time.sleep(0.01)
         self.ndim, self.slots, self.startind = int(hdr[1]), int(hdr[2]), int(hdr[3])
+        self.server_pid = int(hdr[7])
         if not (0 <= slot < self.slots):
             raise ValueError(f"slot {slot} outside the broker's {self.slots} slots")
         self.slot = int(slot)
@@ -263,21 +299,40 @@ class BrokerClient:
             bits, pend = self._bits, self._pending
             bits[0] = pend
             self._row[:] = p                                # (raises for a wrong length)
-            self._req[0] += np.uint32(1)
+            words = self._req
+            seq = words[0] + np.uint32(1)
+            words[0] = seq
             n = 0
-            while bits[0] == pend:
+            # answered: the slot no longer holds the pending pattern, or -- should the answer itself be that pattern -- the
+            # workgroup's acknowledgement (written behind the result) carries this request's number
+            while bits[0] == pend and words[2] != seq:
                 n += 1
-                if not (n & 0xFFFF) and v.hdr[4]:
-                    raise RuntimeError("the likelihood broker has stopped")
+                if not (n & 0x3FFF):
+                    self._still_served(n)
             return float(v.res[s])
         self._row[:] = p                                    # (raises for a wrong length)
         seq = v.req[s] + np.uint64(1)
         v.req[s] = seq                                      # theta first, then the request
         ack = v.ack
+        n = 0
         while ack[s] != seq:
-            if v.hdr[4]:
-                raise RuntimeError("the likelihood broker has stopped")
+            n += 1
+            if not (n & 0x3FFF):
+                self._still_served(n)
         return float(v.logl[s])
+
+    def _still_served(self, n):
+        """Called every 16384 looks of a waiting call: raise when nobody is going to answer -- the stop flag is up, the
+        server process is gone (no flag is raised by a process that dies), or the call has waited `call_timeout` seconds."""
+        if self.v.hdr[4]:
+            raise RuntimeError("the likelihood broker has stopped")
+        if n == 0x4000:
+            self._t_wait = time.monotonic()
+            return
+        if self.server_pid and not _process_alive(self.server_pid):
+            raise RuntimeError(f"the likelihood broker's process ({self.server_pid}) is gone")
+        if self.call_timeout is not None and time.monotonic() - self._t_wait > self.call_timeout:
+            raise RuntimeError(f"the likelihood broker did not answer within {self.call_timeout} s")
 
     def lnlhood_pc(self, p):
         return self.lnlhood_worker(p), []

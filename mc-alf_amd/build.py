@@ -1,4 +1,8 @@
-"""Build libmcalf_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libmcalf_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+The library is five translation units: kernels.hip (every kernel: the only file compiled for the device) and the host
+side of the C ABI -- host_abi.cpp, host_stream.cpp, broker.cpp, comm.cpp -- compiled as plain C++ against the HIP
+runtime API.  Objects are kept under csrc/obj/ so that an edit of a host file does not recompile the kernels (22 s)."""
 from __future__ import annotations
 
 import hashlib
@@ -7,54 +11,98 @@ import shutil
 import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["mcalf_hip.hip"]
-HEADERS = ["voigt_device.h", "voigt_tables.h", os.path.join("..", "..", "include", "mcalf_hip.h")]
-HASHED = ["mcalf_hip.hip", "voigt_device.h", "voigt_tables.h"]
-HOST_MARKER = b"// Host side: context + C ABI"
+KERNEL_SOURCE = "kernels.hip"
+HOST_SOURCES = ["host_abi.cpp", "host_stream.cpp", "broker.cpp", "comm.cpp"]
+SOURCES = [KERNEL_SOURCE] + HOST_SOURCES
+# what the DEVICE code is made of: the kernel-source hash covers exactly these
+HASHED = ["kernels.hip", "kernel_args.h", "voigt_device.h", "voigt_tables.h"]
+HOST_HEADERS = ["host_ctx.h", "kernel_args.h", "voigt_tables.h", os.path.join("..", "..", "include", "mcalf_hip.h")]
 TARGET = os.path.join(CSRC, "libmcalf_hip.so")
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
+OBJDIR = os.path.join(CSRC, "obj")
+ROCM_INCLUDE = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include")
+KERNEL_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
+HOST_FLAGS = ["-x", "c++", "-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__", "-I" + ROCM_INCLUDE]
 
 
-def _stale():
-    if not os.path.exists(TARGET):
+def _hipcc() -> str:
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _mtime(name: str) -> float:
+    return os.path.getmtime(os.path.join(CSRC, name))
+
+
+def _deps(src: str):
+    return [src] + (HASHED if src == KERNEL_SOURCE else HOST_HEADERS)
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(TARGET)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    t = os.path.getmtime(target)
+    return any(_mtime(d) > t for d in deps)
 
 
 def source_hash() -> str:
-    """sha256 over the kernel sources (the device part of mcalf_hip.hip, voigt_device.h, voigt_tables.h), 16 hex digits.  The library
-    carries it (mcalf_version()), the PMC-derived files under profiles/ are stamped with it, and bench.py drops
-    their figures when the two differ -- a kernel edit cannot ship stale utilisation numbers."""
+    """sha256 over the kernel sources (kernels.hip, kernel_args.h, voigt_device.h, voigt_tables.h), 16 hex digits.  The
+    library carries it (mcalf_version()), the PMC-derived files under profiles/ are stamped with it, and bench.py drops
+    their figures when the two differ -- a kernel edit cannot ship stale utilisation numbers, and an edit of the host
+    side of the C ABI (the .cpp files) does not change what the counters measured."""
     h = hashlib.sha256()
     for f in HASHED:
         with open(os.path.join(CSRC, f), "rb") as fh:
-            data = fh.read()
-        if f == "mcalf_hip.hip":
-            # the DEVICE part of the file only (everything above the host-side section): an edit of the C ABI's
-            # host code does not change what the counters measured
-            cut = data.find(HOST_MARKER)
-            if cut < 0:
-                raise RuntimeError("mcalf_hip.hip no longer contains its host-section marker")
-            data = data[:cut]
-        h.update(data)
+            h.update(fh.read())
     return h.hexdigest()[:16]
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP library if it is missing or older than its sources."""
-    if not force and not _stale():
-        return TARGET
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + [f'-DMCALF_SRC_HASH="{source_hash()}"', "-o", TARGET] + SOURCES
-    if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
+def _run(cmd, verbose=False):
     res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("hipcc failed (%s):\n%s%s" % (" ".join(cmd), res.stdout, res.stderr))
     if verbose:
         print(res.stderr)
-    return TARGET
+
+
+def build(force: bool = False, verbose: bool = False, testing: bool = False, target: str | None = None) -> str:
+    """Compile the HIP library if it is missing or older than its sources.
+
+    testing=True builds the TEST variant (-DMCALF_TESTING: the failure-injection hooks MCALF_TEST_FAIL_PREFLIGHT and
+    MCALF_TEST_XCD_MASK exist only there) into `target` -- never the in-tree product library; it shares the product's
+    kernel object, so only the host files are recompiled."""
+    if testing and not target:
+        raise ValueError("a testing build needs an explicit target outside the product path")
+    target = target or TARGET
+    objdir = OBJDIR + ("_testing" if testing else "")
+    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+    stamp = source_hash()
+    objs = []
+    relinked = False
+    # the kernel object (shared by both variants); the hash it was built from is kept next to it
+    kobj = os.path.join(OBJDIR, "kernels.o")
+    kstamp = kobj + ".hash"
+    have = open(kstamp).read().strip() if os.path.exists(kstamp) else ""
+    if (force and not testing) or have != stamp or _stale(kobj, _deps(KERNEL_SOURCE)):
+        cmd = [hipcc] + KERNEL_FLAGS + ["-c", KERNEL_SOURCE, "-o", kobj]
+        if verbose:
+            cmd.append("-Rpass-analysis=kernel-resource-usage")
+        _run(cmd, verbose)
+        with open(kstamp, "w") as fh:
+            fh.write(stamp)
+        relinked = True
+    objs.append(kobj)
+    for src in HOST_SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        # (host_abi.cpp carries the hash string: it is recompiled when the kernels changed)
+        if force or relinked or _stale(obj, _deps(src)):
+            cmd = [hipcc] + HOST_FLAGS + [f'-DMCALF_SRC_HASH="{stamp}"'] + (["-DMCALF_TESTING"] if testing else []) + ["-c", src, "-o", obj]
+            _run(cmd)
+            relinked = True
+        objs.append(obj)
+    if relinked or not os.path.exists(target) or any(os.path.getmtime(o) > os.path.getmtime(target) for o in objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs + ["-ldl"])
+    return target
 
 
 if __name__ == "__main__":

@@ -1,0 +1,1009 @@
+// libmcalf_hip.so, host side: contexts and the C ABI of include/mcalf_hip.h -- creation, launches of the batch kernels,
+// the device-pointer and host-pointer entries, prior transform, diagnostics.  (The streaming launch of large host-pointer
+// batches is host_stream.cpp, the resident evaluator and the likelihood broker broker.cpp, the RCCL gather comm.cpp; the
+// kernels are kernels.hip.)  There is no CPU fallback: every entry point fails with MCALF_ERR_NODEVICE when no gfx950
+// device is present.
+#include <cmath>
+#include <new>
+
+#include "host_ctx.h"
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+
+int set_err(mcalf_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+static int pick_device(mcalf_ctx* ctx, int requested, int* out_dev, std::string* arch) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return set_err(ctx, MCALF_ERR_NODEVICE, "no HIP device available (%s); libmcalf_hip has no CPU fallback",
+                       e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    int dev = requested;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= count) return set_err(ctx, MCALF_ERR_INVALID, "device %d out of range (count %d)", dev, count);
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(ctx, MCALF_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only", dev,
+                       prop.gcnArchName);
+    *out_dev = dev;
+    if (arch) *arch = prop.gcnArchName;
+    return MCALF_OK;
+}
+
+static int upload_tables(mcalf_ctx* ctx, double** d_tabs) {
+    HIP_TRY(ctx, hipMalloc((void**)d_tabs, sizeof(VT_T_HOST)));
+    HIP_TRY(ctx, hipMemcpy(*d_tabs, VT_T_HOST, sizeof(VT_T_HOST), hipMemcpyHostToDevice));
+    return MCALF_OK;
+}
+
+#ifndef MCALF_SRC_HASH
+#define MCALF_SRC_HASH "unstamped"      // mc-alf_amd/build.py passes the sha256 of the kernel sources
+#endif
+extern "C" const char* mcalf_version(void) { return "mcalf_hip 0.3 (gfx950, abi " MCALF_STR(MCALF_ABI_VERSION) ") src " MCALF_SRC_HASH; }
+
+extern "C" const char* mcalf_last_error(const mcalf_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_last_error.c_str();
+}
+
+extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
+    if (!ctx) return;
+    stream_trace_report(ctx);
+    (void)hipSetDevice(ctx->device);
+    comm_release(ctx);
+    resident_stop(ctx);
+    if (ctx->res_stream) (void)hipStreamDestroy(ctx->res_stream);
+    if (ctx->h_box) (void)hipHostFree((void*)ctx->h_box);
+    if (ctx->d_res_shared) (void)hipFree(ctx->d_res_shared);
+    void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_err, ctx->d_tabs, ctx->d_lines, ctx->d_wtab, ctx->d_segok,
+                    ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds, ctx->d_prior, ctx->d_recs, ctx->d_taps, ctx->d_hdr,
+                    ctx->d_queue, ctx->d_order, ctx->d_sws};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (ctx->h_ctl) (void)hipHostFree((void*)ctx->h_ctl);
+    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (hipEvent_t e : ctx->ev_join)
+        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : ctx->aux)
+        if (st) (void)hipStreamDestroy(st);
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
+    if (ctx->ev_kernels) (void)hipEventDestroy(ctx->ev_kernels);
+    for (hipEvent_t e : ctx->ev_comm)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
+    if (!sp) return set_err(ctx, MCALF_ERR_INVALID, "spec is NULL");
+    if (sp->npix <= 0 || !sp->wl || !sp->flux || !sp->err)
+        return set_err(ctx, MCALF_ERR_INVALID, "npix must be > 0 and wl/flux/err non-NULL");
+    if (sp->npix > (1 << 30)) return set_err(ctx, MCALF_ERR_RANGE, "npix too large");
+    if (sp->nlines <= 0 || !sp->lines) return set_err(ctx, MCALF_ERR_INVALID, "need at least one line");
+    if (sp->ncompmax < 0 || sp->nfill < 0) return set_err(ctx, MCALF_ERR_INVALID, "negative component counts");
+    if (!(sp->velstep > 0.0)) return set_err(ctx, MCALF_ERR_INVALID, "velstep must be > 0");
+    if (sp->conv_mode != MCALF_CONV_WRAP_NUMPY && sp->conv_mode != MCALF_CONV_SAME_EDGE_JAX)
+        return set_err(ctx, MCALF_ERR_INVALID, "unknown conv_mode %d", sp->conv_mode);
+    double rmax = sp->specres_max;
+    if (!sp->freespecres && !(rmax >= sp->specres_fixed)) rmax = sp->specres_fixed;
+    if (!(rmax > 0.0) || !std::isfinite(rmax))
+        return set_err(ctx, MCALF_ERR_INVALID, "specres_max must be finite and > 0");
+
+    int rc = pick_device(ctx, sp->device, &ctx->device, &ctx->arch);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    ctx->npix = sp->npix;
+    ctx->nlines = sp->nlines;
+    ctx->ncompmax = sp->ncompmax;
+    ctx->nfill = sp->nfill;
+    ctx->freespecres = sp->freespecres ? 1 : 0;
+    ctx->freecont = sp->freecont ? 1 : 0;
+    ctx->conv_mode = sp->conv_mode;
+    ctx->specres_fixed = sp->specres_fixed;
+    ctx->specres_max = rmax;
+    ctx->contval_fixed = sp->contval_fixed;
+    ctx->velstep = sp->velstep;
+    ctx->asymm = sp->asymmlike ? 1 : 0;                                  // hires_fitter.py:296-303
+    ctx->veto4 = sp->asymm_n4 + 0.01 * (double)sp->npix;                 // gauss_cdf[1] + gracenum (:181,302)
+    ctx->veto5 = sp->asymm_n5 + 0.01 * (double)sp->npix;                 // gauss_cdf[2] + gracenum (:300)
+    ctx->startind = ctx->freecont + ctx->freespecres;             // hires_fitter.py:169-174
+    ctx->endind = ctx->startind + 3 * ctx->ncompmax + 1;          // :176
+    ctx->ndim = ctx->endind + 3 * ctx->nfill;                     // :184-200
+
+    // LSF reach and tiling
+    const double sigma_max = (rmax / kFwhmToSigma) / sp->velstep;
+    if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX) {
+        ctx->jax_half = (int)std::ceil((float)(kKernelReach * sigma_max));   // :557-559 (float32 ceil)
+        ctx->n_cap = ctx->jax_half;
+        if (2L * ctx->jax_half + 1 > ctx->npix)
+            return set_err(ctx, MCALF_ERR_INVALID,
+                           "JAX-path LSF kernel (%d taps) is longer than the spectrum (%ld px): the reference's "
+                           "jnp.convolve(..., 'same') / jnp.where (hires_fitter.py:674-681) cannot broadcast either",
+                           2 * ctx->jax_half + 1, ctx->npix);
+    } else {
+        ctx->n_cap = (rmax > sp->velstep) ? (int)std::ceil(kKernelReach * sigma_max) : 0;
+    }
+    ctx->ncl_cap = std::max(1, ctx->ncompmax * ctx->nlines + ctx->nfill);
+    // Lines per barrier: 5 when that saves a barrier at the context's largest line count and the extra folded
+    // tables cost no tile pixels (LDS), else 4.
+    auto fixed_for = [&](int lps) {
+        return 2 * (size_t)lps * kTabPad + (size_t)ctx->ncl_cap * kRecStride + (2 * (size_t)ctx->n_cap + 8) + kRedDoubles +
+               64 * VT_INODES;
+    };
+    auto ext_for = [&](int lps) {
+        size_t e = kExtMax;
+        while (e > 0 && (fixed_for(lps) + tile_doubles((int)e)) * sizeof(double) > kLdsBudget) e -= 64;
+        return e;
+    };
+    ctx->lps = ((ctx->ncl_cap + 4) / 5 < (ctx->ncl_cap + 3) / 4 && ext_for(5) == ext_for(4)) ? 5 : 4;
+    if (const char* e = std::getenv("MCALF_LINES_PER_SYNC")) {
+        const int v = std::atoi(e);
+        if (v == 4 || (v == 5 && ext_for(5) == ext_for(4))) ctx->lps = v;
+    }
+    const size_t fixed_doubles = fixed_for(ctx->lps);
+    size_t ext = ext_for(ctx->lps);
+    if (ext < 2 * (size_t)ctx->n_cap + 64)
+        return set_err(ctx, MCALF_ERR_RANGE,
+                       "LSF half-width %d px (specres_max %.3g km/s at %.3g km/s/px) with %d component-lines does not "
+                       "fit a %d-pixel workgroup tile / the %zu-byte LDS budget", ctx->n_cap, rmax, sp->velstep,
+                       ctx->ncl_cap, kExtMax, kLdsBudget);
+    // tiles are multiples of 8 pixels (the epilogue works in aligned groups of 8), balanced over the spectrum
+    const long tmax = ((long)ext - 2 * ctx->n_cap) & ~7L;
+    long tile = std::min(tmax, (ctx->npix + 7) & ~7L);
+    long ntiles = (ctx->npix + tile - 1) / tile;
+    tile = (((ctx->npix + ntiles - 1) / ntiles) + 7) & ~7L;
+    ntiles = (ctx->npix + tile - 1) / tile;
+    ctx->tile = (int)tile;
+    ctx->ntiles = (int)ntiles;
+    ctx->lds_bytes = (fixed_doubles + (size_t)tile_doubles((int)tile + 2 * ctx->n_cap)) * sizeof(double);
+    ctx->lds_bytes_inline = (fixed_for(4) + (size_t)tile_doubles((int)tile + 2 * ctx->n_cap)) * sizeof(double);
+    ctx->selfhalo = (ntiles == 1 && ctx->n_cap < ctx->npix) ? 1 : 0;
+
+    // spectrum arrays (float64 host arithmetic identical to the reference's numpy expressions)
+    // Self-halo contexts index nu by thread (0 .. kExtMax-1): the entries past the spectrum are VIRTUAL pixels.
+    // Up to the next multiple of 64 they continue the wavelength grid when it is recognisably linear or
+    // logarithmic over its last 64 pixels (so that the last, partial segment can be interpolated like the
+    // others; the virtual pixels' own results are never stored); beyond that they repeat the last value.
+    const long nu_len = ctx->selfhalo ? (long)kExtMax : ctx->npix;
+    std::vector<double> nu(nu_len), is2(ctx->npix), lg(ctx->npix);
+    for (long i = 0; i < ctx->npix; ++i) {
+        const double wave_cm = sp->wl[i] / 1e8;            // :376
+        nu[i] = kCcgs / wave_cm;                           // :362 at zp1 = 1
+        is2[i] = 1.0 / (sp->err[i] * sp->err[i]);          // :292
+        lg[i] = std::log(is2[i]);                          // :294
+    }
+    if (ctx->selfhalo) {
+        const long n = ctx->npix, upto = std::min<long>(nu_len, (n + 63) & ~63L);
+        int kind = 0;                                      // 1 linear, 2 logarithmic
+        if (n >= 66) {
+            const double d = sp->wl[n - 1] - sp->wl[n - 2], r = sp->wl[n - 1] / sp->wl[n - 2];
+            bool lin = true, lg_ = true;
+            for (long i = n - 64; i < n - 1; ++i) {
+                if (!(std::fabs((sp->wl[i + 1] - sp->wl[i]) - d) <= 1e-9 * std::fabs(d))) lin = false;
+                if (!(std::fabs(sp->wl[i + 1] / sp->wl[i] - r) <= 1e-9 * std::fabs(r - 1.0))) lg_ = false;
+            }
+            kind = lin ? 1 : (lg_ ? 2 : 0);
+        }
+        // the common step from the pixels 64 apart (averages the grid's own rounding noise)
+        const double step = kind == 1 ? (sp->wl[n - 1] - sp->wl[n - 65]) / 64.0
+                          : kind == 2 ? std::exp(std::log(sp->wl[n - 1] / sp->wl[n - 65]) / 64.0) : 0.0;
+        for (long i = n; i < nu_len; ++i) {
+            if (kind != 0 && i < upto) {
+                const double m = (double)(i - (n - 1));
+                const double wl = kind == 1 ? sp->wl[n - 1] + m * step : sp->wl[n - 1] * std::pow(step, m);
+                nu[i] = kCcgs / (wl / 1e8);
+            } else {
+                // past the last (partial) segment nothing is ever stored: nu = 0 puts these lanes at u = -nu0/dnu,
+                // thousands of Doppler widths away from every line, so their segments go the cheap node-only way
+                nu[i] = (i >= upto) ? 0.0 : nu[i - 1];
+            }
+        }
+    }
+    std::vector<LineDev> lines(ctx->nlines + 1);
+    for (int l = 0; l <= ctx->nlines; ++l) {
+        const mcalf_line& src = (l < ctx->nlines) ? sp->lines[l] : sp->fill;
+        lines[l].wrest_cm = src.wrest_A / 1e8;             // :376
+        lines[l].f = src.f;
+        lines[l].gamma4pi = src.gamma / (4.0 * M_PI);      // :361
+        lines[l].nujk = kCcgs / lines[l].wrest_cm;         // :359
+    }
+    const size_t nb = (size_t)ctx->npix * sizeof(double);
+    const size_t nbp = nb + 8 * sizeof(double);          // the epilogue reads 8 pixels per thread without a bounds test
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_nu, (size_t)nu_len * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_obj, nbp));
+    HIP_TRY(ctx, hipMemset(ctx->d_obj, 0, nbp));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_ispec2, nbp));
+    HIP_TRY(ctx, hipMemset(ctx->d_ispec2, 0, nbp));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_lgis, nbp));
+    HIP_TRY(ctx, hipMemset(ctx->d_lgis, 0, nbp));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_err, nbp));
+    HIP_TRY(ctx, hipMemset(ctx->d_err, 0, nbp));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_lines, lines.size() * sizeof(LineDev)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_nu, nu.data(), (size_t)nu_len * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_obj, sp->flux, nb, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_ispec2, is2.data(), nb, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_lgis, lg.data(), nb, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_err, sp->err, nb, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_lines, lines.data(), lines.size() * sizeof(LineDev), hipMemcpyHostToDevice));
+    rc = upload_tables(ctx, &ctx->d_tabs);
+    if (rc) return rc;
+
+    // Far-wing interpolation set-up: which 64-pixel segments of each tile may be interpolated in
+    // pixel-index space.  A segment qualifies when it lies inside the tile's extent without crossing
+    // the periodic seam and nu(pixel) itself is reproduced by the 8-node interpolant to 1e-15 (true
+    // for linear / logarithmic wavelength grids, false across masked gaps).
+    std::vector<unsigned long long> segok(ctx->ntiles, 0ULL);
+    double dnu_seg = 0.0;
+    for (int t = 0; t < ctx->ntiles; ++t) {
+        const long t0 = (long)t * ctx->tile;
+        const long tlen = std::min<long>(ctx->tile, ctx->npix - t0);
+        const long ext0 = ctx->selfhalo ? 0 : t0 - ctx->n_cap, extCount = tlen + 2L * ctx->n_cap;
+        for (int m = 0; m < 64; ++m) {
+            const long i0 = 64L * m;
+            const long e0 = ext0 + i0;
+            if (ctx->selfhalo) {
+                if (e0 + 63 >= nu_len) continue;
+                if (e0 >= ((ctx->npix + 63) & ~63L)) {          // wholly virtual (nu = 0): nothing to get wrong
+                    segok[t] |= 1ULL << m;
+                    continue;
+                }
+                // otherwise: real pixels, the last segment completed by the virtual continuation of the grid
+            } else {
+                if (i0 + 64 > extCount) continue;
+                if (e0 < 0 || e0 + 63 >= ctx->npix) continue;
+            }
+            bool ok = true;
+            const double dir = nu[e0 + 63] - nu[e0];
+            for (int i = 0; i < 64 && ok; ++i) {
+                double v = 0.0;
+                for (int k = 0; k < VT_INODES; ++k) v += VT_INTERP_W_HOST[i * VT_INODES + k] * nu[e0 + VT_INTERP_NODES[k]];
+                const double x = nu[e0 + i];
+                if (!std::isfinite(x) || !(std::fabs(v - x) <= 1e-15 * std::fabs(x))) ok = false;
+                if (i > 0 && !((nu[e0 + i] - nu[e0 + i - 1]) * dir > 0.0)) ok = false;   // strictly monotonic
+            }
+            if (!ok) continue;
+            segok[t] |= 1ULL << m;
+            dnu_seg = std::max(dnu_seg, std::fabs(dir));
+        }
+    }
+    ctx->dnu_seg = dnu_seg;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_segok, segok.size() * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_segok, segok.data(), segok.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_wtab, sizeof(VT_INTERP_W_HOST)));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_wtab, VT_INTERP_W_HOST, sizeof(VT_INTERP_W_HOST), hipMemcpyHostToDevice));
+    // more than 64 KiB of dynamic LDS needs the attribute (2 workgroups x 78 KiB fit the 160 KiB of a CU)
+    for (int k = 0; k < fused_kernel_count(); ++k)
+        HIP_TRY(ctx, hipFuncSetAttribute(fused_kernel_at(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    if ((rc = create_stream(ctx, &ctx->stream))) return rc;
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if ((rc = stream_probe_xcds(ctx))) return rc;         // (the streaming launch is for one device shape only)
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_queue, kMaxChunks * sizeof(unsigned int)));
+        HIP_TRY(ctx, hipMemset(ctx->d_queue, 0, kMaxChunks * sizeof(unsigned int)));
+        const char* pe = std::getenv("MCALF_PERSIST");
+        if (pe && *pe) ctx->persist = std::atoi(pe) != 0;
+        if (const char* oe = std::getenv("MCALF_ORDER")) ctx->ordered = std::atoi(oe) != 0;
+        ctx->inline_max_items = 2 * ctx->num_cu;                    // launches that fit the chip in one round of workgroups
+        if (const char* ie = std::getenv("MCALF_INLINE_MAX")) ctx->inline_max_items = std::max(0, std::atoi(ie));
+        if (const char* re = std::getenv("MCALF_RESIDENT_US")) ctx->resident_us = std::min(1000000, std::max(0, std::atoi(re)));
+        if (const char* sb = std::getenv("MCALF_SETUP_BLOCK")) {      // diagnostic: geometry of the set-up kernel
+            const int v = std::atoi(sb);
+            if (v >= 64 && v <= kSetupBlockMax && v % 64 == 0) ctx->setup_block = v;
+        }
+        if (const char* hp = std::getenv("MCALF_HOST_PLAN")) {      // e.g. "1,3,4": relative block sizes (diagnostic)
+            int n = 0;
+            for (const char* q = hp; *q && n < kMaxChunks;) {
+                const int v = std::atoi(q);
+                if (v > 0) ctx->host_plan[n++] = v;
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+            if (n > 0) ctx->host_plan_n = n;
+        }
+#ifdef MCALF_TESTING
+        if (const char* fp = std::getenv("MCALF_TEST_FAIL_PREFLIGHT")) ctx->fail_preflight = std::atoi(fp) != 0;
+#endif
+        if (const char* e = std::getenv("MCALF_STREAM")) ctx->stream_on = std::min(std::max(std::atoi(e), 0), 2);
+        if (const char* e = std::getenv("MCALF_STREAM_WGS")) ctx->stream_wgs = std::min(std::max(std::atoi(e), 1), ctx->num_cu);
+        if (const char* e = std::getenv("MCALF_STREAM_POLL")) ctx->stream_poll = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MCALF_STREAM_EAGER")) ctx->stream_eager = std::max(std::atoi(e), 0);
+        if (const char* e = std::getenv("MCALF_STREAM_CHUNK")) ctx->stream_chunk = std::min(std::max(std::atoi(e) & ~7, 8), 512);
+        if (const char* e = std::getenv("MCALF_STREAM_DEVICE")) ctx->stream_device = std::atoi(e);
+        if (const char* e = std::getenv("MCALF_STREAM_TRACE")) ctx->stream_trace = std::atoi(e) != 0;
+        if (const char* e = std::getenv("MCALF_STREAM_TIMEOUT")) { const double v = std::atof(e); if (v > 0.0 && v <= 60.0) ctx->stream_timeout_s = v; }
+
+        const char* env = std::getenv("MCALF_CHUNKS");            // 0 / unset: automatic; n: exactly n row blocks
+        if (env && *env) {
+            const int v = std::atoi(env);
+            if (v >= 0 && v <= kMaxChunks) ctx->chunks_req = v;
+        }
+    }
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_create(const mcalf_spec* spec, mcalf_ctx** out) {
+    if (!out) return set_err(nullptr, MCALF_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    mcalf_ctx* ctx = new (std::nothrow) mcalf_ctx();
+    if (!ctx) return set_err(nullptr, MCALF_ERR_NOMEM, "out of host memory");
+    int rc = create_impl(spec, ctx);
+    if (rc != MCALF_OK) {
+        g_last_error = ctx->err;
+        mcalf_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_info(const mcalf_ctx* ctx, mcalf_info_t* info) {
+    if (!ctx || !info) return set_err(nullptr, MCALF_ERR_INVALID, "NULL argument");
+    memset(info, 0, sizeof *info);
+    info->abi_version = MCALF_ABI_VERSION;
+    info->ndim = ctx->ndim;
+    info->startind = ctx->startind;
+    info->endind = ctx->endind;
+    info->n_cap = ctx->n_cap;
+    info->tile = ctx->tile;
+    info->ntiles = ctx->ntiles;
+    info->device = ctx->device;
+    info->npix = ctx->npix;
+    snprintf(info->arch, sizeof info->arch, "%s", ctx->arch.c_str());
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_last_launch(const mcalf_ctx* ctx, mcalf_launch_info_t* info) {
+    if (!ctx || !info) return set_err(nullptr, MCALF_ERR_INVALID, "NULL argument");
+    *info = ctx->last;
+    info->xcd_mask = (int32_t)ctx->xcd_mask;
+    return MCALF_OK;
+}
+
+// A stream of the context: non-blocking, or -- with a CU mask (mcalf_set_cu_mask) -- restricted to the mask's CUs.
+int create_stream(mcalf_ctx* ctx, hipStream_t* out) {
+    if (ctx->cu_mask.empty()) HIP_TRY(ctx, hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    else HIP_TRY(ctx, hipExtStreamCreateWithCUMask(out, (uint32_t)ctx->cu_mask.size(), ctx->cu_mask.data()));
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_set_cu_mask(mcalf_ctx* ctx, const uint32_t* mask, int32_t nwords) {
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    if (nwords < 0 || nwords > 64 || (nwords > 0 && !mask)) return set_err(ctx, MCALF_ERR_INVALID, "CU mask: 0 .. 64 words");
+    bool any = nwords == 0;
+    for (int32_t i = 0; i < nwords; ++i) any = any || mask[i] != 0u;
+    if (!any) return set_err(ctx, MCALF_ERR_INVALID, "CU mask selects no compute unit");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the context's own streams are idle between its (synchronous) host-pointer calls; wait anyway, then replace them
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (hipStream_t& st : ctx->aux)
+        if (st) { HIP_TRY(ctx, hipStreamSynchronize(st)); HIP_TRY(ctx, hipStreamDestroy(st)); st = nullptr; }
+    HIP_TRY(ctx, hipStreamDestroy(ctx->stream));
+    ctx->stream = nullptr;
+    ctx->cu_mask.assign(mask, mask + nwords);
+    int rc = create_stream(ctx, &ctx->stream);
+    if (rc != MCALF_OK) {                                 // (a mask the runtime refuses: back to an unrestricted stream)
+        ctx->cu_mask.clear();
+        const std::string why = ctx->err;
+        if (create_stream(ctx, &ctx->stream) != MCALF_OK) return rc;
+        (void)stream_probe_xcds(ctx);
+        return set_err(ctx, rc, "%s (the context keeps an unrestricted stream)", why.c_str());
+    }
+    return stream_probe_xcds(ctx);
+}
+
+static int grow_sample_ws(mcalf_ctx* ctx, int64_t batch) {
+    int rc;
+    if ((rc = grow(ctx, &ctx->d_recs, &ctx->cap_recs, (size_t)batch * ctx->ncl_cap * kRecStride))) return rc;
+    if ((rc = grow(ctx, &ctx->d_taps, &ctx->cap_taps, (size_t)batch * (2 * (size_t)ctx->n_cap + 8)))) return rc;
+    if ((rc = grow(ctx, &ctx->d_hdr, &ctx->cap_hdr, (size_t)batch))) return rc;
+    if ((rc = grow(ctx, &ctx->d_order, &ctx->cap_order, (size_t)batch))) return rc;
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_reserve(mcalf_ctx* ctx, int64_t batch) {
+    if (!ctx || batch < 0) return set_err(ctx, MCALF_ERR_INVALID, "bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, (size_t)batch * std::max(ctx->ndim, 5)))) return rc;
+    if ((rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
+    if ((rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4))) return rc;
+    if ((rc = grow_sample_ws(ctx, batch))) return rc;
+    return MCALF_OK;
+}
+
+// Enqueue rows [row0, row0 + nrows) of a batch on `stream`: set-up kernel, fused kernel, finalize when tiled.
+// `chunk` selects the row of the shared tap table this block writes and reads (fixed-resolution contexts).
+// `from_cube`: dP holds unit-cube rows, mapped through the prior box while decoding; d_theta (optional)
+// receives the transformed rows.
+// The kernel arguments of rows [row0, row0 + nrows) of a batch (everything but the launch geometry).
+KArgs make_kargs(const mcalf_ctx* ctx, int mode, const double* dP, int64_t row0, int64_t nrows, int chunk,
+                        int targonly, int onecomp_fill, double* d_out, double* d_model, bool from_cube, double* d_theta) {
+    const int rowlen = (mode == kModeOneComp) ? 5 : ctx->ndim;
+    const size_t tapTotal = 2 * (size_t)ctx->n_cap + 8;
+    KArgs a = {};
+    a.taps_shared = (!ctx->freespecres && mode != kModeOneComp) ? 1 : 0;
+    a.recs = ctx->d_recs + (size_t)row0 * ctx->ncl_cap * kRecStride;
+    a.taps = ctx->d_taps + (a.taps_shared ? (size_t)chunk : (size_t)row0) * tapTotal;
+    a.hdr = ctx->d_hdr + row0;
+    a.nu = ctx->d_nu; a.obj = ctx->d_obj; a.ispec2 = ctx->d_ispec2; a.lgis = ctx->d_lgis; a.err = ctx->d_err;
+    a.asymm = (mode == kModeLogL) ? ctx->asymm : 0; a.veto4 = ctx->veto4; a.veto5 = ctx->veto5;
+    a.P = dP + (size_t)row0 * rowlen;
+    a.partial = ctx->d_partial ? ctx->d_partial + (size_t)row0 * ctx->ntiles * 4 : nullptr;
+    a.out = d_out ? d_out + row0 : nullptr;
+    a.model = d_model ? d_model + (size_t)row0 * ctx->npix : nullptr;
+    a.lines = ctx->d_lines; a.tabs = ctx->d_tabs; a.wtab = ctx->d_wtab; a.segok = ctx->d_segok; a.dnu_seg = ctx->dnu_seg;
+    a.npix = (int)ctx->npix; a.ndim = ctx->ndim; a.ntiles = ctx->ntiles; a.tile = ctx->tile;
+    a.n_cap = ctx->n_cap; a.ncl_cap = ctx->ncl_cap;
+    a.nlines = ctx->nlines; a.ncompmax = ctx->ncompmax; a.nfill = ctx->nfill;
+    a.startind = ctx->startind; a.endind = ctx->endind;
+    a.freespecres = ctx->freespecres; a.freecont = ctx->freecont;
+    a.targonly = targonly; a.mode = mode; a.jax_half = ctx->jax_half; a.onecomp_fill = onecomp_fill;
+    a.selfhalo = ctx->selfhalo;
+    a.specres_fixed = ctx->specres_fixed; a.contval_fixed = ctx->contval_fixed; a.velstep = ctx->velstep;
+    a.log2pi = std::log(2.0 * M_PI);
+    a.prior_lo = from_cube ? ctx->d_prior : nullptr;
+    a.prior_hi = from_cube ? ctx->d_prior + ctx->ndim : nullptr;
+    a.theta_out = (from_cube && d_theta) ? d_theta + (size_t)row0 * ctx->ndim : nullptr;
+    a.prior_int = ctx->prior_int;
+    a.nitems = (int)(nrows * ctx->ntiles);
+    a.nrows = (int)nrows;
+    a.queue = ctx->d_queue + chunk;
+    return a;
+}
+
+// The finalize kernel of a tiled spectrum behind the fused kernel of `a` (adds the per-tile partials in fixed order).
+int launch_finalize(mcalf_ctx* ctx, const KArgs& a, int64_t nrows, int mode, hipStream_t stream) {
+    const int fb = 256;
+    const double* partial = a.partial;
+    double* out = a.out;
+    long n = (long)nrows;
+    int ntiles = ctx->ntiles, m = mode, asymm = a.asymm;
+    double v4 = a.veto4, v5 = a.veto5;
+    void* fargs[] = {(void*)&partial, (void*)&out, (void*)&n, (void*)&ntiles, (void*)&m, (void*)&asymm, (void*)&v4, (void*)&v5};
+    HIP_TRY(ctx, hipLaunchKernel(finalize_kernel_ptr(), dim3((unsigned)((nrows + fb - 1) / fb)), dim3(fb), fargs, 0, stream));
+    return MCALF_OK;
+}
+
+static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0, int64_t nrows, int chunk,
+                        int targonly, int onecomp_fill, double* d_out, double* d_model, hipStream_t stream,
+                        bool from_cube, double* d_theta, bool timed_ok) {
+    const bool reduces = (mode == kModeLogL || mode == kModeChi2);
+    KArgs a = make_kargs(ctx, mode, dP, row0, nrows, chunk, targonly, onecomp_fill, d_out, d_model, from_cube, d_theta);
+    // Persistent grid = the workgroup slots of the chip (2 per CU: LDS and the 4 waves per SIMD the kernel's
+    // registers allow); correctness does not depend on how many of them are resident at once.  Used once every
+    // slot sees at least four items: measured on MI355X, 8 items per slot (config C) -3.5 % and 160 per slot
+    // (config E) -12 % in kernel time, but 2 per slot (config B) +2 % -- there the queue and the prefetch cost
+    // more than the two workgroup launches they replace, so small launches keep one workgroup per item.
+    const int64_t slots = 2LL * ctx->num_cu;
+    a.persist = (ctx->persist && a.nitems >= 4 * slots) ? 1 : 0;
+    // Ordered hand-out while a slot sees at most 16 items: measured on MI355X, config C's spectrum, -2.2 % kernel time
+    // at 8 items per slot (4096 live points) and nothing at 64 (32768), where the ordering workgroup -- its keys no
+    // longer fit its registers -- would lengthen the set-up kernel by 47 us instead.
+    a.order = (a.persist && ctx->ordered && ctx->selfhalo && mode != kModeOneComp && a.nitems <= 16 * slots)
+                  ? ctx->d_order + row0 : nullptr;
+    const dim3 grid((unsigned)(a.persist ? slots : a.nitems)), block(kBlock);
+    ctx->last.persistent = a.persist; ctx->last.grid = (int32_t)grid.x; ctx->last.items = a.nitems;
+    ctx->last.lines_per_sync = ctx->lps; ctx->last.selfhalo = ctx->selfhalo; ctx->last.ordered = a.order ? 1 : 0;
+    // Small launches (the one-theta-at-a-time solvers, a handful of live points): ONE kernel, every workgroup sets
+    // its live point up itself (mcalf_fused_kernel<..., kInline = true>) -- the set-up kernel and the dependent-launch
+    // gap behind it are a fifth of such a call's latency.  Same set-up code, same bits.
+    const bool inl = !a.persist && a.nitems <= ctx->inline_max_items;
+    ctx->last.inline_setup = inl ? 1 : 0;
+    if (!inl) {
+        const int per_wg = ctx->setup_block / 64;             // live points per set-up workgroup (one wave each)
+        const dim3 sgrid((unsigned)((nrows + per_wg - 1) / per_wg) + (a.order ? 1u : 0u)), sblock((unsigned)ctx->setup_block);
+        long nrows_arg = (long)nrows;
+        void* sargs[] = {(void*)&a, (void*)&nrows_arg};
+        HIP_TRY(ctx, hipLaunchKernel(sample_kernel_ptr(ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX), sgrid, sblock, sargs, 0, stream));
+    }
+    const bool timed = timed_ok && ctx->profiling && ctx->ev_used + 2 <= ctx->ev.size();
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used], stream));
+    {
+        void* kargs[] = {(void*)&a};
+        HIP_TRY(ctx, hipLaunchKernel(fused_kernel_ptr(ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX, ctx->selfhalo != 0, ctx->lps, inl),
+                                     grid, block, kargs, inl ? ctx->lds_bytes_inline : ctx->lds_bytes, stream));
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    if (timed) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], stream));
+        ctx->ev_used += 2;
+    }
+    if (reduces && ctx->ntiles > 1) return launch_finalize(ctx, a, nrows, mode, stream);
+    return MCALF_OK;
+}
+
+// Row blocks a *_device batch is issued in.  Automatic = ONE: measured on MI355X (config C, 4096 live points), every
+// extra block costs ~20 us of cross-stream event traffic and buys nothing, because the persistent fused kernel
+// leaves no launch tail for the next block to fill (0.267 / 0.287 / 0.309 / 0.327 ms per batch with 1 / 2 / 3 / 4
+// blocks).  The knob stays for callers that want to interleave their own work, and for the host-pointer entry,
+// where blocks overlap the PCIe copies with the kernels (run_host_pipelined).
+static int pick_chunks(const mcalf_ctx* ctx, int64_t batch) {
+    int n = ctx->chunks_req > 0 ? ctx->chunks_req : 1;
+    if (n > kMaxChunks) n = kMaxChunks;
+    if ((int64_t)n > batch) n = (int)batch;
+    return n < 1 ? 1 : n;
+}
+
+static int ensure_aux(mcalf_ctx* ctx, int naux) {
+    if (!ctx->ev_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < naux; ++i) {
+        if (!ctx->aux[i]) {
+            const int rc = create_stream(ctx, &ctx->aux[i]);
+            if (rc) return rc;
+        }
+        if (!ctx->ev_join[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
+    }
+    return MCALF_OK;
+}
+
+static int64_t chunk_begin(int64_t batch, int nchunks, int c) { return batch * c / nchunks; }
+
+// Enqueue one batch on `stream` (asynchronous).  With several row blocks, blocks 1.. go to the context's
+// auxiliary streams between a fork event recorded on `stream` and join events `stream` waits for, so the call
+// keeps plain stream semantics for the caller (and can be captured into a hipGraph).
+// Everything of a launch that can fail WITHOUT anything having been enqueued: the range check and the growth of
+// the per-sample workspaces (hipMalloc).  The collective entry runs it before it enqueues anything, so that a rank
+// that fails here can still take its part in the exchange (mcalf_loglike_gatherv_device).
+int launch_preflight(mcalf_ctx* ctx, int mode, int64_t batch) {
+    if (batch == 0) return MCALF_OK;
+    if (batch < 0 || batch * (int64_t)ctx->ntiles > 0x7fff0000LL)
+        return set_err(ctx, MCALF_ERR_RANGE, "batch %lld too large", (long long)batch);
+    const bool reduces = (mode == kModeLogL || mode == kModeChi2);
+    int rc;
+#ifdef MCALF_TESTING
+    if (ctx->fail_preflight) return set_err(ctx, MCALF_ERR_NOMEM, "workspace growth failed (injected by MCALF_TEST_FAIL_PREFLIGHT)");
+#endif
+    if (reduces && ctx->ntiles > 1 && (rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4)))
+        return rc;
+    return grow_sample_ws(ctx, batch);
+}
+
+int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill,
+           double* d_out, double* d_model, hipStream_t stream, bool from_cube, double* d_theta) {
+    if (batch == 0) return MCALF_OK;
+    int rc;
+    // MCALF_STREAM_DEVICE=1 (diagnostic): device-pointer batches through the streaming single launch as well -- every
+    // row is there from the start, so the whole grid sets up eight live points per workgroup and goes on to the items
+    if (ctx->stream_device && (mode == kModeLogL || mode == kModeChi2) && !from_cube && !d_model && ctx->chunks_req <= 1 &&
+        stream_qualifies(ctx, batch) && ctx->xcd_mask == (1u << kXcds) - 1u) {
+        if ((rc = stream_prepare(ctx, mode, batch))) return rc;
+        ctx->last.row_blocks = 1;
+        if (ctx->stream_device == 2) {                     // ... with the host entries' split: a few rows eagerly, the rest by dedicated workgroups
+            const int grid = 2 * ctx->num_cu, wgs = std::min((ctx->stream_wgs + kXcds - 1) / kXcds * kXcds, grid / 2 / kXcds * kXcds);
+            const int64_t first_rows = ((grid - wgs) / kXcds + ctx->ntiles - 1) / ctx->ntiles;
+            return stream_launch(ctx, mode, dP, batch, d_out, stream, wgs, (first_rows + 7) / 8, false, false);
+        }
+        return stream_launch(ctx, mode, dP, batch, d_out, stream, 0, batch, false, false);
+    }
+    if ((rc = launch_preflight(ctx, mode, batch))) return rc;
+    const int nchunks = ctx->profiling ? 1 : pick_chunks(ctx, batch);
+    ctx->last.row_blocks = nchunks;
+    if (nchunks == 1)
+        return launch_range(ctx, mode, dP, 0, batch, 0, targonly, onecomp_fill, d_out, d_model, stream, from_cube,
+                            d_theta, true);
+    if ((rc = ensure_aux(ctx, nchunks - 1))) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, stream));
+    for (int c = 0; c < nchunks; ++c) {
+        const int64_t r0 = chunk_begin(batch, nchunks, c), r1 = chunk_begin(batch, nchunks, c + 1);
+        hipStream_t st = (c == 0) ? stream : ctx->aux[c - 1];
+        if (c > 0) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_fork, 0));
+        if ((rc = launch_range(ctx, mode, dP, r0, r1 - r0, c, targonly, onecomp_fill, d_out, d_model, st, from_cube,
+                               d_theta, false)))
+            return rc;
+        if (c > 0) HIP_TRY(ctx, hipEventRecord(ctx->ev_join[c - 1], st));
+    }
+    for (int c = 1; c < nchunks; ++c) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->ev_join[c - 1], 0));
+    return MCALF_OK;
+}
+
+extern "C" int32_t mcalf_get_chunks(const mcalf_ctx* ctx, int64_t batch) {
+    return (ctx && batch > 0) ? pick_chunks(ctx, batch) : 0;
+}
+
+extern "C" int mcalf_set_chunks(mcalf_ctx* ctx, int32_t nchunks) {
+    if (!ctx || nchunks < 0 || nchunks > kMaxChunks)
+        return set_err(ctx, MCALF_ERR_INVALID, "nchunks must be 0 (automatic) .. %d", kMaxChunks);
+    ctx->chunks_req = nchunks;
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_profile_begin(mcalf_ctx* ctx, int32_t max_launches) {
+    if (!ctx || max_launches <= 0) return set_err(ctx, MCALF_ERR_INVALID, "bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    while (ctx->ev.size() < 2 * (size_t)max_launches) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev.push_back(e);
+    }
+    ctx->ev_used = 0;
+    ctx->profiling = true;
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_profile_end(mcalf_ctx* ctx, double* mean_ms, int32_t* launches) {
+    if (!ctx || !mean_ms) return set_err(ctx, MCALF_ERR_INVALID, "bad arguments");
+    ctx->profiling = false;
+    double sum = 0.0;
+    const size_t n = ctx->ev_used / 2;
+    for (size_t i = 0; i < n; ++i) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2 * i + 1]));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
+        sum += ms;
+    }
+    *mean_ms = n ? sum / (double)n : 0.0;
+    if (launches) *launches = (int32_t)n;
+    ctx->ev_used = 0;
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_loglike_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, double* dlogL,
+                                          void* stream) {
+    if (!ctx || (batch > 0 && (!dP || !dlogL))) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->last.path = MCALF_PATH_DEVICE; ctx->last.pinned_in = ctx->last.pinned_out = 0;
+    return launch(ctx, kModeLogL, dP, batch, 0, 0, dlogL, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int mcalf_model_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, int32_t targonly,
+                                        double* dflux, void* stream) {
+    if (!ctx || (batch > 0 && (!dP || !dflux))) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->last.path = MCALF_PATH_DEVICE; ctx->last.pinned_in = ctx->last.pinned_out = 0;
+    return launch(ctx, kModeModel, dP, batch, targonly ? 1 : 0, 0, nullptr, dflux, (hipStream_t)stream);
+}
+
+
+// True when `p` is page-locked host memory the copy engines can read / write directly.
+bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();                          // ordinary pageable memory: not an error for us
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+// Large scalar-output batches through host pointers: the rows are cut into blocks that alternate between two
+// streams, each block being  H2D of its parameter rows -> set-up + fused kernels -> D2H of its results,  so the
+// PCIe traffic and the per-block set-up of block k+1 run under the kernels of block k.  Pageable caller memory
+// is staged through a page-locked block of the context (the host copies block k+1 in while the GPU works on
+// block k); page-locked caller memory is used by the copy engines directly.
+static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly,
+                              int fill, double* out_scalar) {
+    int rc;
+    // Row blocks: an explicit request gives equal blocks; the automatic plan is a SMALL first block (the GPU starts
+    // after one eighth of the input has arrived) followed by larger ones (large launches run the persistent grid
+    // and leave fewer tails).  Measured on MI355X, config C (device-resident 0.251 ms per batch): pageable input
+    // 1:1:2:4 0.311 ms, 1:3:4 0.319, 2:6 0.320, four equal blocks 0.333, one block 0.351; page-locked input (no
+    // staging copy on the host thread) 1:7 0.297, 2:6 0.301, 1:1:2:4 0.307, four equal blocks 0.321.
+    const bool pin_in = is_pinned_host(P), pin_out = is_pinned_host(out_scalar);
+    int weights[kMaxChunks];
+    int nchunks = 0;
+    if (ctx->chunks_req > 0) {
+        for (nchunks = 0; nchunks < ctx->chunks_req && nchunks < kMaxChunks; ++nchunks) weights[nchunks] = 1;
+    } else if (ctx->host_plan_n > 0) {
+        for (nchunks = 0; nchunks < ctx->host_plan_n; ++nchunks) weights[nchunks] = ctx->host_plan[nchunks];
+    } else if (pin_in) {
+        weights[0] = 1; weights[1] = 7; nchunks = 2;
+    } else {
+        weights[0] = 1; weights[1] = 1; weights[2] = 2; weights[3] = 4; nchunks = 4;
+    }
+    if ((int64_t)nchunks > batch) nchunks = (int)batch;
+    if (ctx->profiling) nchunks = 1;
+    int64_t bounds[kMaxChunks + 1];
+    {
+        int total = 0, run = 0;
+        for (int c = 0; c < nchunks; ++c) total += weights[c];
+        bounds[0] = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            run += weights[c];
+            bounds[c + 1] = batch * run / total;
+        }
+    }
+    if ((rc = ensure_aux(ctx, 1))) return rc;
+    const bool reduces = (mode == kModeLogL || mode == kModeChi2);
+    if (reduces && ctx->ntiles > 1 && (rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4)))
+        return rc;
+    if ((rc = grow_sample_ws(ctx, batch))) return rc;
+    const size_t need = (pin_in ? 0 : (size_t)batch * rowlen) + (pin_out ? 0 : (size_t)batch);
+    if (need > ctx->cap_stage) {
+        if (ctx->h_stage) HIP_TRY(ctx, hipHostFree(ctx->h_stage));
+        ctx->h_stage = nullptr; ctx->cap_stage = 0;
+        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_stage, need * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        ctx->cap_stage = need;
+    }
+    double* stage_in = pin_in ? nullptr : ctx->h_stage;
+    double* stage_out = pin_out ? out_scalar : ctx->h_stage + (pin_in ? 0 : (size_t)batch * rowlen);
+    // Results: the kernels write logL straight into the page-locked block (its device address), 8 bytes per live
+    // point over PCIe, which saves the D2H copy command of every block -- the last one is on the critical path.
+    double* d_stage_out = nullptr;
+    if (hipHostGetDevicePointer((void**)&d_stage_out, stage_out, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        d_stage_out = nullptr;                            // (caller's page-locked memory that is not device-mapped)
+    }
+    ctx->last.path = MCALF_PATH_HOST_PIPELINED; ctx->last.row_blocks = nchunks;
+    ctx->last.pinned_in = pin_in ? 1 : 0; ctx->last.pinned_out = pin_out ? 1 : 0;
+    hipStream_t streams[2] = {ctx->stream, ctx->aux[0]};
+    // A failure in block k leaves blocks < k in flight on both streams, reading the staging block / the caller's
+    // page-locked rows and writing the caller's results: never return under them (the next call may free the
+    // staging block, the caller its arrays).  Every error below therefore leaves through `fail`.
+    hipError_t he = hipSuccess;
+    const char* what = "";
+    rc = MCALF_OK;
+    for (int c = 0; c < nchunks && rc == MCALF_OK && he == hipSuccess; ++c) {
+        const int64_t r0 = bounds[c], n = bounds[c + 1] - r0;
+        if (n == 0) continue;
+        hipStream_t st = streams[c & 1];
+        const double* src = P + (size_t)r0 * rowlen;
+        if (!pin_in) {
+            std::memcpy(stage_in + (size_t)r0 * rowlen, src, (size_t)n * rowlen * sizeof(double));
+            src = stage_in + (size_t)r0 * rowlen;
+        }
+        he = hipMemcpyAsync(ctx->d_P + (size_t)r0 * rowlen, src, (size_t)n * rowlen * sizeof(double), hipMemcpyHostToDevice, st);
+        if (he != hipSuccess) { what = "H2D copy of a row block"; break; }
+        rc = launch_range(ctx, mode, ctx->d_P, r0, n, c, targonly, fill, d_stage_out ? d_stage_out : ctx->d_out, nullptr, st,
+                          false, nullptr, nchunks == 1);
+        if (rc != MCALF_OK) break;
+        if (!d_stage_out) {
+            he = hipMemcpyAsync(stage_out + r0, ctx->d_out + r0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
+            if (he != hipSuccess) { what = "D2H copy of a result block"; break; }
+        }
+    }
+    const hipError_t s0 = hipStreamSynchronize(ctx->stream);
+    const hipError_t s1 = (nchunks > 1) ? hipStreamSynchronize(ctx->aux[0]) : hipSuccess;
+    if (rc != MCALF_OK) return rc;                                   // (message set by launch_range)
+    if (he != hipSuccess) return set_err(ctx, MCALF_ERR_HIP, "%s failed: %s", what, hipGetErrorString(he));
+    if (s0 != hipSuccess || s1 != hipSuccess)
+        return set_err(ctx, MCALF_ERR_HIP, "stream synchronisation failed: %s", hipGetErrorString(s0 != hipSuccess ? s0 : s1));
+    if (!pin_out) std::memcpy(out_scalar, stage_out, (size_t)batch * sizeof(double));
+    return MCALF_OK;
+}
+
+// The page-locked, device-mapped block small calls go through: parameters in its first half, results in its second.
+int ensure_small(mcalf_ctx* ctx) {
+    if (!ctx->h_small) {
+        // (coherent: the host fills the result slots before a launch and reads them while it runs)
+        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_small, 2 * kSmallDoubles * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->d_small, ctx->h_small, 0));
+    }
+    return MCALF_OK;
+}
+
+// Small scalar-output calls (up to kSmallDoubles parameters: single-theta calls, config B's batch), zero-copy: a
+// single-theta call is dominated by the latency of its two copy commands.  from_cube / theta_out: as in run_host_stream.
+static int run_host_small(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
+                          double* out_scalar, bool from_cube, double* theta_out) {
+    int rc;
+    if (resident_serves(ctx, mode, batch, rowlen, from_cube)) return resident_call(ctx, P, rowlen, out_scalar);
+    if ((rc = ensure_small(ctx))) return rc;
+    std::memcpy(ctx->h_small, P, (size_t)batch * rowlen * sizeof(double));
+    ctx->last.path = MCALF_PATH_HOST_ZEROCOPY; ctx->last.pinned_in = ctx->last.pinned_out = 0;
+    // Completion is read off the results: their slots are filled with a NaN no kernel produces, and the call is over
+    // when none is left -- a stream wait costs an interrupt and a thread wake-up on top of the kernel, a fifth of a
+    // one-theta call.  (The stream is asked now and then, so that a failed launch cannot keep the call here.)
+    uint64_t* res = reinterpret_cast<uint64_t*>(ctx->h_small + kSmallDoubles);
+    const bool poll = ctx->stream_poll != 0;
+    if (poll)
+        for (int64_t i = 0; i < batch; ++i) __atomic_store_n(res + i, kResultPending, __ATOMIC_RELEASE);
+    rc = launch(ctx, mode, ctx->d_small, batch, targonly, fill, ctx->d_small + kSmallDoubles, nullptr, ctx->stream, from_cube);
+    if (rc) return rc;
+    if (theta_out) host_scale_cube(ctx, P, batch, theta_out);       // (under the launch)
+    bool done = false;
+    if (poll) {
+        int64_t left = batch;                            // results [left, batch) have been seen
+        for (unsigned long spins = 1;; ++spins) {
+            while (left > 0 && __atomic_load_n(res + left - 1, __ATOMIC_ACQUIRE) != kResultPending) --left;
+            if (left == 0) { done = true; break; }
+            if ((spins & 0x3FFFul) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;
+            __builtin_ia32_pause();
+        }
+    }
+    if (!done) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->last.stream_polled = done ? 1 : 0;
+    std::memcpy(out_scalar, ctx->h_small + kSmallDoubles, (size_t)batch * sizeof(double));
+    return MCALF_OK;
+}
+
+// Host-pointer entries: stage through the context's workspaces on its private stream.
+static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
+                    double* out_scalar, double* out_model) {
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    if (batch < 0) return set_err(ctx, MCALF_ERR_INVALID, "negative batch");
+    if (batch == 0) return MCALF_OK;
+    if (!P || (!out_scalar && !out_model)) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if (out_scalar && !out_model && (size_t)batch * rowlen <= kSmallDoubles && (size_t)batch <= kSmallDoubles)
+        return run_host_small(ctx, mode, P, batch, rowlen, targonly, fill, out_scalar, false, nullptr);
+    if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, (size_t)batch * rowlen))) return rc;
+    if (out_scalar && (rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
+    if (out_model && (rc = grow(ctx, &ctx->d_model, &ctx->cap_model, (size_t)batch * ctx->npix))) return rc;
+    if (out_scalar && !out_model) {
+        if (mode == kModeLogL || mode == kModeChi2) {
+            bool taken = false;
+            if ((rc = run_host_stream(ctx, mode, P, batch, rowlen, out_scalar, &taken)) != MCALF_OK || taken) return rc;
+        }
+        return run_host_pipelined(ctx, mode, P, batch, rowlen, targonly, fill, out_scalar);
+    }
+    ctx->last.path = MCALF_PATH_HOST_STAGED; ctx->last.pinned_in = ctx->last.pinned_out = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_P, P, (size_t)batch * rowlen * sizeof(double), hipMemcpyHostToDevice,
+                                ctx->stream));
+    rc = launch(ctx, mode, ctx->d_P, batch, targonly, fill, out_scalar ? ctx->d_out : nullptr,
+                out_model ? ctx->d_model : nullptr, ctx->stream);
+    if (rc) return rc;
+    if (out_scalar)
+        HIP_TRY(ctx, hipMemcpyAsync(out_scalar, ctx->d_out, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    if (out_model)
+        HIP_TRY(ctx, hipMemcpyAsync(out_model, ctx->d_model, (size_t)batch * ctx->npix * sizeof(double),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_loglike_batch(mcalf_ctx* ctx, const double* P, int64_t batch, double* logL) {
+    return run_host(ctx, kModeLogL, P, batch, ctx ? ctx->ndim : 0, 0, 0, logL, nullptr);
+}
+
+extern "C" int mcalf_chi2_batch(mcalf_ctx* ctx, const double* P, int64_t batch, double* chi2) {
+    return run_host(ctx, kModeChi2, P, batch, ctx ? ctx->ndim : 0, 0, 0, chi2, nullptr);
+}
+
+extern "C" int mcalf_model_batch(mcalf_ctx* ctx, const double* P, int64_t batch, int32_t targonly, double* flux) {
+    return run_host(ctx, kModeModel, P, batch, ctx ? ctx->ndim : 0, targonly ? 1 : 0, 0, nullptr, flux);
+}
+
+extern "C" int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batch, int32_t which, double* flux) {
+    if (ctx && (which < 0 || which >= 2 + ctx->nlines))
+        return set_err(ctx, MCALF_ERR_INVALID, "onecomp: `which` must be 0 (all lines), 1 (filler) or 2+k with k < %d",
+                       ctx->nlines);
+    return run_host(ctx, kModeOneComp, Q, batch, 5, 0, which, nullptr, flux);
+}
+
+extern "C" int mcalf_set_prior(mcalf_ctx* ctx, const double* lo, const double* hi, int32_t int_ncomp) {
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    if (!lo || !hi) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_prior) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_prior, 2 * (size_t)ctx->ndim * sizeof(double)));
+    // synchronous copies: the caller's arrays are borrowed for this call only, and a later *_device call may
+    // run on any stream
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_prior, lo, ctx->ndim * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_prior + ctx->ndim, hi, ctx->ndim * sizeof(double), hipMemcpyHostToDevice));
+    ctx->h_prior.assign(lo, lo + ctx->ndim);
+    ctx->h_prior.insert(ctx->h_prior.end(), hi, hi + ctx->ndim);
+    ctx->prior_set = true;
+    ctx->prior_int = int_ncomp ? 1 : 0;
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_loglike_cube_batch_device(mcalf_ctx* ctx, const double* dcube, int64_t batch, double* dtheta,
+                                               double* dlogL, void* stream) {
+    if (!ctx || (batch > 0 && (!dcube || !dlogL))) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    if (!ctx->prior_set) return set_err(ctx, MCALF_ERR_INVALID, "mcalf_set_prior has not been called");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->last.path = MCALF_PATH_DEVICE; ctx->last.pinned_in = ctx->last.pinned_out = 0;
+    return launch(ctx, kModeLogL, dcube, batch, 0, 0, dlogL, nullptr, (hipStream_t)stream, true, dtheta);
+}
+
+extern "C" int mcalf_loglike_cube_batch(mcalf_ctx* ctx, const double* cube, int64_t batch, double* theta,
+                                        double* logL) {
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    if (batch < 0) return set_err(ctx, MCALF_ERR_INVALID, "negative batch");
+    if (!ctx->prior_set) return set_err(ctx, MCALF_ERR_INVALID, "mcalf_set_prior has not been called");
+    if (batch == 0) return MCALF_OK;
+    if (!cube || !logL) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t total = (size_t)batch * ctx->ndim;
+    int rc;
+    // the paths of mcalf_loglike_batch, with the prior transform applied while the rows are decoded and the transformed
+    // rows formed on the host under the launch: the zero-copy small call, ONE streaming launch for large batches
+    if (total <= kSmallDoubles && (size_t)batch <= kSmallDoubles)
+        return run_host_small(ctx, kModeLogL, cube, batch, ctx->ndim, 0, 0, logL, true, theta);
+    {
+        bool taken = false;
+        if ((rc = run_host_stream(ctx, kModeLogL, cube, batch, ctx->ndim, logL, &taken, true, theta)) != MCALF_OK || taken) return rc;
+    }
+    // otherwise (tiled spectra, explicit row blocks): staged copies, the transformed rows come back from the device
+    ctx->last.path = MCALF_PATH_HOST_STAGED; ctx->last.pinned_in = ctx->last.pinned_out = 0;
+    if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, total))) return rc;
+    if ((rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
+    if (theta && (rc = grow(ctx, &ctx->d_model, &ctx->cap_model, total))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_P, cube, total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = launch(ctx, kModeLogL, ctx->d_P, batch, 0, 0, ctx->d_out, nullptr, ctx->stream, true,
+                theta ? ctx->d_model : nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(logL, ctx->d_out, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (theta)
+        HIP_TRY(ctx, hipMemcpyAsync(theta, ctx->d_model, total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_scale_cube_batch(mcalf_ctx* ctx, const double* lo, const double* hi, const double* cube,
+                                      int64_t batch, int32_t int_ncomp, double* theta) {
+    if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    if (batch < 0) return set_err(ctx, MCALF_ERR_INVALID, "negative batch");
+    if (batch == 0) return MCALF_OK;
+    if (!lo || !hi || !cube || !theta) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t total = (size_t)batch * ctx->ndim;
+    int rc;
+    if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, total))) return rc;
+    if ((rc = grow(ctx, &ctx->d_model, &ctx->cap_model, total))) return rc;
+    if (!ctx->d_bounds) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bounds, 2 * (size_t)ctx->ndim * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bounds, lo, ctx->ndim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bounds + ctx->ndim, hi, ctx->ndim * sizeof(double), hipMemcpyHostToDevice,
+                                ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_P, cube, total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    {
+        const double *lo_d = ctx->d_bounds, *hi_d = ctx->d_bounds + ctx->ndim, *cube_d = ctx->d_P;
+        long n = (long)total;
+        int nd = ctx->ndim, slot = ctx->startind, as_int = int_ncomp;
+        double* theta_d = ctx->d_model;
+        void* kargs[] = {(void*)&lo_d, (void*)&hi_d, (void*)&cube_d, (void*)&n, (void*)&nd, (void*)&slot, (void*)&as_int, (void*)&theta_d};
+        HIP_TRY(ctx, hipLaunchKernel(scale_cube_kernel_ptr(), dim3((unsigned)((total + 255) / 256)), dim3(256), kargs, 0, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(theta, ctx->d_model, total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MCALF_OK;
+}
+
+static int hjerting_impl(const double* x, const double* y, int64_t n, double* out, int32_t device, int node_form) {
+    if (n < 0 || (n > 0 && (!x || !y || !out))) return set_err(nullptr, MCALF_ERR_INVALID, "bad arguments");
+    if (n == 0) return MCALF_OK;
+    int dev = 0;
+    int rc = pick_device(nullptr, device, &dev, nullptr);
+    if (rc) return rc;
+    HIP_TRY(nullptr, hipSetDevice(dev));
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr, *dtabs = nullptr;
+    const size_t nb = (size_t)n * sizeof(double);
+    hipError_t em = hipMalloc((void**)&dx, nb);
+    if (em == hipSuccess) em = hipMalloc((void**)&dy, nb);
+    if (em == hipSuccess) em = hipMalloc((void**)&dout, nb);
+    if (em != hipSuccess) rc = set_err(nullptr, MCALF_ERR_HIP, "hjerting: hipMalloc failed: %s", hipGetErrorString(em));
+    else rc = upload_tables(nullptr, &dtabs);
+    if (rc == MCALF_OK) {
+        hipError_t e = hipMemcpy(dx, x, nb, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dy, y, nb, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            long cnt = (long)n;
+            void* kargs[] = {(void*)&dx, (void*)&dy, (void*)&cnt, (void*)&dout, (void*)&dtabs, (void*)&node_form};
+            e = hipLaunchKernel(hjert_kernel_ptr(), dim3((unsigned)((n + 255) / 256)), dim3(256), kargs, 0, nullptr);
+        }
+        if (e == hipSuccess) e = hipMemcpy(out, dout, nb, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = set_err(nullptr, MCALF_ERR_HIP, "hjerting: %s", hipGetErrorString(e));
+    }
+    for (double* b : {dx, dy, dout, dtabs})
+        if (b) (void)hipFree(b);
+    return rc;
+}
+
+extern "C" int mcalf_voigt_hjerting(const double* x, const double* y, int64_t n, double* out, int32_t device) {
+    return hjerting_impl(x, y, n, out, device, 0);
+}
+
+extern "C" int mcalf_voigt_hjerting_nodes(const double* x, const double* y, int64_t n, double* out, int32_t device) {
+    return hjerting_impl(x, y, n, out, device, 1);
+}
+
+

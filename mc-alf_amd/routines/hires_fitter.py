@@ -17,7 +17,6 @@ replaced by an explicit `linepars=` argument plus a tiny built-in table (`LINE_T
 from __future__ import annotations
 
 import ctypes as C
-import weakref
 import gc
 from typing import Optional, Sequence
 
@@ -32,6 +31,25 @@ LINE_TABLE = {
     "CIV 1550": (1550.781, 0.09475, 2.628e8),
     "HI 1215": (1215.67, 0.4164, 6.265e8),
 }
+
+# The atomic constants the reference itself holds: after the database look-up it REPLACES f and gamma of three CrII
+# lines (hires_fitter.py:100-110, "from atomic database in RCooke ALIS code"); wrest stays the database's.
+LINE_OVERRIDES = {
+    "CrII 2066": dict(f=0.0512, gamma=4.17e8),
+    "CrII 2062": dict(f=0.0759, gamma=4.06e8),
+    "CrII 2056": dict(f=0.103, gamma=4.07e8),
+}
+
+
+def apply_line_overrides(fitlines, linepars):
+    """`linepars` = [(wrest, f, gamma), ...] as a database returned them for `fitlines`, with the reference's in-file
+    overrides applied by line name (hires_fitter.py:100-110).  `wrest` must still come from the caller: the linetools
+    'ISM' list the reference reads it from is not available here."""
+    out = []
+    for name, (w, f, g) in zip(fitlines, linepars):
+        o = LINE_OVERRIDES.get(name)
+        out.append((float(w), float(o["f"]), float(o["gamma"])) if o else (float(w), float(f), float(g)))
+    return out
 
 
 def sigma_clipped_median(x, sigma=3.0, maxiters=5):
@@ -96,7 +114,8 @@ class als_fitter:
     def __init__(self, specfile, fitrange, fitlines, ncomp, nfill=0, specres=[7.0], contval=[1.0],
                  Nrange=[11.5, 16], brange=[1, 30], zrange=None, Nrangefill=[11.5, 16], brangefill=[1, 30],
                  wrangefill=None, coldef=['Wave', 'Flux', 'Err'], Gpriors=None, Asymmlike=False, debug=False,
-                 *, spectrum=None, linepars=None, velstep=None, conv_mode="numpy", device=-1, gauss_cdf=None):
+                 *, spectrum=None, linepars=None, velstep=None, conv_mode="numpy", device=-1, gauss_cdf=None,
+                 database_linepars=False):
         # public attributes under the names the reference's callers read (hires_fitter.py:46-60)
         self.specfile, self.fitrange, self.fitlines = specfile, fitrange, fitlines
         self.Gpriors, self.Asymmlike, self.debug = Gpriors, bool(Asymmlike), debug
@@ -134,6 +153,10 @@ class als_fitter:
                 linepars = [LINE_TABLE[name] for name in fitlines]
             except KeyError as exc:
                 raise KeyError(f"line {exc} is not in the built-in table; pass linepars=[(wrest,f,gamma),...]")
+        if len(linepars) != self.numlines:
+            raise ValueError(f"{self.numlines} fit lines but {len(linepars)} (wrest, f, gamma) triples")
+        if database_linepars:                          # :100-110: the caller's triples are raw database values
+            linepars = apply_line_overrides(fitlines, linepars)
         self.linepars = [dict(wrest=float(w), f=float(f), gamma=float(g)) for (w, f, g) in linepars]
         self.linefill = dict(self.linepars[0])         # :120-121
         self.linefill["wrest"] = 250.0
@@ -236,21 +259,16 @@ class als_fitter:
         self._p1 = np.empty((1, self.ndim))
         self._o1 = np.empty(1)
         self._p1_ptr, self._o1_ptr = self._p1.ctypes.data, self._o1.ctypes.data
-        self._ptrs = {}
 
     def _ptr(self, arr):
-        """Address of a C-contiguous array's data (cached per array object: `ndarray.ctypes` costs a microsecond)."""
-        hit = self._ptrs.get(id(arr))
-        if hit is not None and hit[0]() is arr:
-            return hit[1]
-        ptr = arr.ctypes.data
-        if len(self._ptrs) >= 16:
-            self._ptrs.clear()
-        try:
-            self._ptrs[id(arr)] = (weakref.ref(arr), ptr)
-        except TypeError:                                   # (an array type that cannot be weakly referenced)
-            pass
-        return ptr
+        """Address of a C-contiguous array's data.  Only the context's OWN persistent one-theta buffers have their address
+        cached (`ndarray.ctypes` costs a microsecond of a 15 us call): a caller's array may be reallocated in place
+        (`ndarray.resize(refcheck=False)`) without changing its identity, so its address is read on every call."""
+        if arr is self._p1:
+            return self._p1_ptr
+        if arr is self._o1:
+            return self._o1_ptr
+        return arr.__array_interface__["data"][0]
 
     def close(self):
         twin = getattr(self, "_twin", None)
@@ -274,6 +292,14 @@ class als_fitter:
         workgroup that stays on the GPU between calls -- no kernel launch per call -- and leaves by itself after `idle_us`
         microseconds without one; 0 turns it off.  Same bits as the launched form."""
         _lib.check(self._lib.mcalf_set_resident(self._ctx, int(idle_us)), self._ctx)
+
+    def set_cu_mask(self, mask_words):
+        """Restrict the context's own streams to the compute units of `mask_words` (uint32 words, bit i of word i // 32 =
+        CU i; empty / None removes the mask) -- `mcalf_set_cu_mask`.  Results never depend on it; on anything but the
+        eight XCDs of an unpartitioned MI355X large host batches take the row-block pipeline (`last_launch()`)."""
+        words = np.ascontiguousarray([] if mask_words is None else mask_words, dtype=np.uint32)
+        ptr = words.ctypes.data_as(C.POINTER(C.c_uint32)) if words.size else None
+        _lib.check(self._lib.mcalf_set_cu_mask(self._ctx, ptr, int(words.size)), self._ctx)
 
     def last_launch(self):
         """What the last call of this context did (`mcalf_last_launch`): entry plan, row blocks, whether the fused

@@ -28,3 +28,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def testing_lib(tmp_path_factory):
+    """The TEST variant of libmcalf_hip.so (-DMCALF_TESTING: only it reads the failure-injection switches
+    MCALF_TEST_FAIL_PREFLIGHT / MCALF_TEST_XCD_MASK), built into a temporary directory from the product's sources and its
+    kernel object; worker processes load it through MCALF_HIP_LIB.  The in-tree product library carries no such hook
+    (tests/test_abi_symbols.py)."""
+    import importlib
+    bld = importlib.import_module("mc-alf_amd.build")
+    out = str(tmp_path_factory.mktemp("testing_lib") / "libmcalf_hip_testing.so")
+    return bld.build(testing=True, target=out)

@@ -39,6 +39,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.mcalf_spec) == 8 + 3 * 8 + 8 + 8 + 8 + 24 + 4 * 4 + 3 * 8 + 2 * 4 + 8 + 2 * 8
     assert C.sizeof(_lib.mcalf_info_t) == 8 * 4 + 8 + 32
     assert C.sizeof(_lib.mcalf_broker_t) == 2 * 4 + 10 * 8
+    assert C.sizeof(_lib.mcalf_launch_info_t) == 4 * 4 + 8 + 10 * 4 == 64
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -60,7 +61,7 @@ def test_product_package_does_not_import_oracle():
     pkg = os.path.join(ROOT, "mc-alf_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h")):
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
 
@@ -112,3 +113,13 @@ def test_null_arguments_do_not_crash():
     assert lib.mcalf_broker_serve(one, 1, None, 0.0) == -1
     assert lib.mcalf_voigt_hjerting(None, None, -1, None, -1) == -1
     assert lib.mcalf_voigt_hjerting(None, None, 0, None, -1) == 0
+    assert lib.mcalf_set_cu_mask(None, None, 0) == -1
+    assert lib.mcalf_stream_partition(8, 0, None, None) == -1 and lib.mcalf_stream_partition(8, 4, None, None) == -1
+
+
+def test_product_library_carries_no_failure_injection_hooks():
+    """MCALF_TEST_* switches exist only in the -DMCALF_TESTING variant the GPU tests build into a temporary directory
+    (mc-alf_amd/build.py: build(testing=True, target=...)); the in-tree product library does not read them."""
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"MCALF_TEST_" not in blob
+    assert b"MCALF_STREAM_TIMEOUT" in blob                 # (the check does see environment names that ARE there)

@@ -58,9 +58,14 @@ def test_library_carries_the_hash_of_the_device_sources():
     bld = importlib.import_module("mc-alf_amd.build")
     lib = mcalf_amd._lib.load()
     assert bench.library_source_hash(lib) == bld.source_hash()            # built by __graft_entry__.build()
-    # the hash covers the device part of mcalf_hip.hip only: the host-section marker must exist exactly once
-    src = open(os.path.join(bld.CSRC, "mcalf_hip.hip"), "rb").read()
-    assert src.count(bld.HOST_MARKER) == 1
+    # the hash covers what the DEVICE code is made of -- the kernels, the argument block they share with the host, the
+    # Voigt function and its tables -- and none of the host side of the C ABI
+    assert bld.HASHED == ["kernels.hip", "kernel_args.h", "voigt_device.h", "voigt_tables.h"]
+    assert not set(bld.HASHED) & set(bld.HOST_SOURCES)
+    kernels = open(os.path.join(bld.CSRC, "kernels.hip")).read()
+    assert 'extern "C"' not in kernels and "__global__" in kernels
+    for f in bld.HOST_SOURCES:                                            # (no device code outside kernels.hip)
+        assert "__global__" not in open(os.path.join(bld.CSRC, f)).read(), f
 
 
 def test_issue_model_arithmetic():

@@ -190,3 +190,131 @@ def test_a_rank_written_in_c_speaks_the_mailbox_protocol_of_the_header(tmp_path)
         del v
         shm.close()
         shm.unlink()
+
+
+def _dying_server(name, ready):
+    b = broker.LikelihoodBroker(FakeFit(), name, slots=2)
+    ready.put(os.getpid())
+    time.sleep(0.5)
+    os._exit(9)                                             # dies without close(): no stop flag is ever raised
+
+
+def test_a_rank_does_not_spin_for_ever_when_the_server_dies_or_never_answers():
+    """A server process that is killed (GPU fault, OOM) raises no stop flag.  The client watches the server's pid (in the
+    header) and its own per-call limit: both end the wait with a RuntimeError instead of a rank at 100 % CPU for ever."""
+    from multiprocessing import shared_memory
+    name = f"mcalf_test_dead_{os.getpid()}"
+    ctx = mp.get_context("spawn")
+    ready = ctx.Queue()
+    srv = ctx.Process(target=_dying_server, args=(name, ready))
+    srv.start()
+    try:
+        pid = ready.get(timeout=60)
+        cl = broker.BrokerClient(name, 0, call_timeout=60.0)
+        assert cl.server_pid == pid
+        t0 = time.time()
+        with pytest.raises(RuntimeError, match="is gone"):
+            cl.lnlhood_pc(np.ones(5))                       # nobody polls: the call waits until the server has died
+        assert time.time() - t0 < 30
+        cl.close()
+    finally:
+        srv.join(timeout=30)
+        try:
+            leftover = shared_memory.SharedMemory(name=name)
+            leftover.close()
+            leftover.unlink()
+        except FileNotFoundError:
+            pass
+    # a server that lives but never serves: the per-call limit
+    name2 = name + "_mute"
+    with broker.LikelihoodBroker(FakeFit(), name2, slots=2):
+        cl = broker.BrokerClient(name2, 1, call_timeout=0.2)
+        t0 = time.time()
+        with pytest.raises(RuntimeError, match="did not answer within 0.2"):
+            cl.lnlhood_dy(np.ones(5))
+        assert time.time() - t0 < 20
+        cl.close()
+
+
+def test_an_evaluator_that_raises_leaves_the_stop_flag_up():
+    """serve() that ends with an exception serves nobody any more: the flag must be up so that waiting ranks raise too."""
+    class Broken(FakeFit):
+        def loglike_batch(self, P):
+            raise ValueError("evaluator failed")
+    name = f"mcalf_test_broken_{os.getpid()}"
+    with broker.LikelihoodBroker(Broken(), name, slots=2) as b:
+        cl = broker.BrokerClient(name, 0)
+        cl._row[:] = np.ones(5)
+        cl.v.req[0] += np.uint64(1)                         # an open request, posted without waiting for it
+        with pytest.raises(ValueError, match="evaluator failed"):
+            b.serve(native=False)
+        assert int(b.v.hdr[4]) == 1
+        with pytest.raises(RuntimeError, match="stopped"):
+            cl.lnlhood_pc(np.ones(5))
+        cl.close()
+
+
+def test_attaching_before_the_header_is_complete_retries_instead_of_crashing():
+    """The block exists before its magic is written.  A rank that attaches in that window must release its view before it
+    closes the mapping (BufferError otherwise) and try again."""
+    import threading
+    from multiprocessing import shared_memory
+    name = f"mcalf_test_early_{os.getpid()}"
+    _, size = broker._layout(FakeFit.ndim, 2)
+    shm = shared_memory.SharedMemory(name=name, create=True, size=size)
+    shm.buf[:size] = bytes(size)
+    v = broker._Views(shm.buf, FakeFit.ndim, 2)
+    try:
+        def finish_header():
+            time.sleep(0.15)
+            v.hdr[1], v.hdr[2], v.hdr[3] = FakeFit.ndim, 2, FakeFit.startind
+            v.hdr[0] = broker._MAGIC
+        th = threading.Thread(target=finish_header)
+        th.start()
+        cl = broker.BrokerClient(name, 1, timeout=10.0)      # (attaches several times before the magic appears)
+        th.join()
+        assert (cl.ndim, cl.slots, cl.startind) == (FakeFit.ndim, 2, FakeFit.startind)
+        cl.close()
+    finally:
+        del v
+        shm.close()
+        shm.unlink()
+
+
+def test_resident_answer_that_equals_the_pending_pattern_is_recognised_by_its_acknowledgement():
+    """Completion of a mailbox call is normally read off the result slot (it no longer holds the pending pattern).  An
+    answer that IS that bit pattern -- a NaN carrying the payload through the arithmetic -- is recognised by the
+    workgroup's acknowledgement instead of stalling the rank."""
+    import threading
+    from multiprocessing import shared_memory
+    name = f"mcalf_test_pend_{os.getpid()}"
+    ndim, slots = FakeFit.ndim, 1
+    _, size = broker._layout_resident(ndim, slots)
+    shm = shared_memory.SharedMemory(name=name, create=True, size=size)
+    shm.buf[:size] = bytes(size)
+    v = broker._ResidentViews(shm.buf, ndim, slots)
+    v.hdr[1], v.hdr[2], v.hdr[3] = ndim, slots, FakeFit.startind
+    v.hdr[0] = broker._MAGIC_RESIDENT
+
+    def workgroup():
+        while not v.hdr[4]:
+            req = v.words[0, 0]
+            if req != v.words[0, 2]:
+                v.res_bits[0] = np.uint64(broker._PENDING)  # the "answer" is the pending pattern itself
+                v.words[0, 2] = req
+            time.sleep(0.0002)
+
+    th = threading.Thread(target=workgroup)
+    th.start()
+    try:
+        cl = broker.BrokerClient(name, 0, call_timeout=20.0)
+        t0 = time.time()
+        got = cl.lnlhood_dy(np.ones(ndim))
+        assert np.isnan(got) and time.time() - t0 < 10
+        cl.close()
+    finally:
+        v.hdr[4] = 1
+        th.join(timeout=10)
+        del v
+        shm.close()
+        shm.unlink()

@@ -34,8 +34,10 @@ def fake_rccl(tmp_path_factory):
     return out
 
 
-def _run(mode, work, fake):
+def _run(mode, work, fake, lib=None):
     env = dict(os.environ, MCALF_RCCL_LIB=fake, HSA_ENABLE_IPC_MODE_LEGACY="0", FAKE_RCCL_DELAY_US="2000")
+    if lib:
+        env["MCALF_HIP_LIB"] = lib                        # (the test variant of the library: failure injection)
     env.pop("MCALF_TEST_FAIL_PREFLIGHT", None)
     env.pop("FAKE_RCCL_SYNC", None)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gather_worker.py"), str(r), "2", work, mode],
@@ -87,8 +89,8 @@ def test_negative_control_one_local_buffer_in_overlap_mode_shows(tmp_path, fake_
     assert not np.array_equal(np.array(got[6])[501:], expected[6][501:])   # ... the one before it is not
 
 
-def test_a_rank_that_fails_locally_sends_nans_and_nobody_hangs(tmp_path, fake_rccl, expected):
-    r0, r1 = _run("fail", str(tmp_path), fake_rccl)
+def test_a_rank_that_fails_locally_sends_nans_and_nobody_hangs(tmp_path, fake_rccl, expected, testing_lib):
+    r0, r1 = _run("fail", str(tmp_path), fake_rccl, testing_lib)
     assert r0["codes"] == [0] * 8                                    # the root is fine ...
     assert r1["codes"] == [_lib.MCALF_ERR_NOMEM] * 8                 # ... rank 1 reports its failure every time
     assert "NaN" in r1["err"] and "MCALF_TEST_FAIL_PREFLIGHT" in r1["err"]

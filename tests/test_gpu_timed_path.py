@@ -281,6 +281,7 @@ def test_streaming_host_entry_one_launch_no_copy_commands(cfg, conv, n, monkeypa
     with mcalf_amd.als_fitter(None, **kw) as fit:
         got = fit.loglike_batch(P)
         assert fit.last_launch().path == _lib.MCALF_PATH_HOST_PIPELINED
+        assert fit.last_launch().stream_fallback == _lib.MCALF_STREAM_FALLBACK_TIMEOUT
         assert np.array_equal(got, ref["logl"])
         # ... and the queues were re-armed: with the limit restored the next context streams again
     monkeypatch.delenv("MCALF_STREAM_TIMEOUT")

@@ -91,3 +91,51 @@ def test_table_reader_accepts_the_usual_plain_text_layouts(tmp_path, style):
         path.write_text("Err, Wave, Flux\n" + "\n".join("%r, %r, %r" % (e, w, f) for w, f, e in rows) + "\n")
     got = hires_fitter._read_ascii_table(str(path), ["Wave", "Flux", "Err"])
     assert np.array_equal(got[0], wl) and np.array_equal(got[1], fl) and np.array_equal(got[2], er)
+
+
+@pytest.mark.parametrize("nxcd", [1, 2, 3, 4, 8, 16])
+@pytest.mark.parametrize("nrows", [0, 1, 7, 8, 9, 63, 64, 65, 1000, 4096, 32768])
+def test_streaming_launch_deals_every_row_to_exactly_one_xcd(nrows, nxcd):
+    """The streaming launch of the host-pointer entries deals the rows of a batch to the XCDs in blocks of eight (block k ->
+    XCD k % nxcd) and only workgroups on an XCD evaluate its rows: `stream_rows_of` / `stream_row` (kernel_args.h -- the
+    constexpr functions the kernels use, reached here through mcalf_stream_partition, pure host arithmetic) must be a
+    bijection between the rows and the (XCD, local index) pairs, with the local indices of an XCD contiguous from 0."""
+    import ctypes as C
+    from mcalf_amd import _lib
+    lib = _lib.load()
+    owner = np.full(max(nrows, 1), -7, dtype=np.int32)
+    local = np.full(max(nrows, 1), -7, dtype=np.int32)
+    pi = C.POINTER(C.c_int32)
+    rc = lib.mcalf_stream_partition(nrows, nxcd, owner.ctypes.data_as(pi), local.ctypes.data_as(pi))
+    assert rc == 0, lib.mcalf_last_error(None)
+    owner, local = owner[:nrows], local[:nrows]
+    assert ((owner >= 0) & (owner < nxcd)).all()                         # every row has an owner (none left at -1)
+    r = np.arange(nrows)
+    assert np.array_equal(owner, (r // 8) % nxcd)                        # block k of eight rows -> XCD k % nxcd
+    for x in range(nxcd):
+        mine = np.sort(local[owner == x])
+        assert np.array_equal(mine, np.arange(mine.size))                # local indices 0 .. n_x - 1, each once
+        rows = r[owner == x]
+        assert np.array_equal(rows[np.argsort(local[owner == x])], rows)  # and in row order: the host stages rows in order
+
+
+def test_crii_overrides_are_the_reference_s_own_constants(nodev):
+    """hires_fitter.py:100-110: after the database look-up the reference REPLACES f and gamma of CrII 2056 / 2062 / 2066
+    (the only atomic constants it holds itself); wrest stays the database's.  With `database_linepars=True` the caller's
+    triples are treated as raw database values and get the same treatment, by line name."""
+    assert hires_fitter.LINE_OVERRIDES == {"CrII 2066": dict(f=0.0512, gamma=4.17e8),
+                                           "CrII 2062": dict(f=0.0759, gamma=4.06e8),
+                                           "CrII 2056": dict(f=0.103, gamma=4.07e8)}
+    names = ["CrII 2056", "CIV 1548", "CrII 2066"]
+    db = [(2056.2569, 0.1, 1.0e8), (1548.204, 0.1899, 2.643e8), (2066.164, 0.05, 1.0e8)]     # (f, gamma: placeholders to be replaced)
+    got = hires_fitter.apply_line_overrides(names, db)
+    assert got == [(2056.2569, 0.103, 4.07e8), (1548.204, 0.1899, 2.643e8), (2066.164, 0.0512, 4.17e8)]
+    wl = np.linspace(8220.0, 8270.0, 400)
+    kw = dict(spectrum=(wl, np.ones_like(wl), np.full_like(wl, 0.02)), linepars=db, zrange=[2.99, 3.01])
+    fit = mcalf_amd.als_fitter(None, [[8220.0, 8270.0]], names, [1, 1], database_linepars=True, **kw)
+    assert [(d["wrest"], d["f"], d["gamma"]) for d in fit.linepars] == got
+    assert fit.linefill == dict(wrest=250.0, f=0.103, gamma=4.07e8)       # :120-121: a copy of line 0, AFTER the override
+    raw = mcalf_amd.als_fitter(None, [[8220.0, 8270.0]], names, [1, 1], **kw)       # explicit triples are taken as given
+    assert [(d["wrest"], d["f"], d["gamma"]) for d in raw.linepars] == db
+    with pytest.raises(ValueError, match="triples"):
+        mcalf_amd.als_fitter(None, [[8220.0, 8270.0]], names, [1, 1], spectrum=kw["spectrum"], linepars=db[:2], zrange=[2.99, 3.01])
