@@ -55,8 +55,9 @@ extern "C" {
                                  3: MCALF_PATH_HOST_STREAM, mcalf_launch_info_t grows by stream_setup_wgs / stream_polled
                                  4: mcalf_broker_serve
                                  5: mcalf_set_resident, mcalf_broker_serve_resident
-                                 6: mcalf_set_cu_mask, mcalf_stream_partition, mcalf_launch_info_t grows by xcd_mask /
-                                    stream_fallback (the streaming launch is taken only on the device shape it was built for) */
+                                 6: mcalf_set_cu_mask, mcalf_stream_partition, mcalf_launch_info_t grows by xcd_mask / stream_wgs_min /
+                                    stream_wgs_max / stream_fallback (the streaming launch is taken only on the device shape it
+                                    was built for, and checked after every launch) */
 
 enum {
     MCALF_OK = 0,
@@ -289,6 +290,8 @@ typedef struct {
                                MCALF_PATH_HOST_ZEROCOPY: 1 = completion read off the results in page-locked memory */
     int32_t xcd_mask;       /* bit i: the context's probe kernel saw workgroups of its stream on XCD i (hardware XCC_ID).  The
                                streaming launch deals rows to XCDs 0 .. 7 and is taken only when this is exactly 0xFF */
+    int32_t stream_wgs_min; /* MCALF_PATH_HOST_STREAM (and a launch discarded as STARVED): the fewest / most workgroups of the */
+    int32_t stream_wgs_max; /* launch an XCD received, counted by the kernel -- every XCD's rows are evaluated by ITS workgroups only */
     int32_t stream_fallback;/* host-pointer entries, what kept the call from being ONE streaming launch although its size asked
                                for one: 0 nothing (or not applicable), MCALF_STREAM_FALLBACK_* otherwise -- the row-block
                                pipeline (MCALF_PATH_HOST_PIPELINED) evaluated the call instead, same bits */
@@ -304,11 +307,13 @@ int mcalf_last_launch(const mcalf_ctx* ctx, mcalf_launch_info_t* info);
 
 /* Restrict the context's own streams (the host-pointer entries; *_device entries run on the CALLER's stream) to the
  * compute units of `mask` -- bit i of word i / 32 = CU i in the runtime's numbering (hipExtStreamCreateWithCUMask; on a
- * multi-XCD device consecutive bits go round the XCDs) -- as an embedding application does to share one GPU between
- * ranks.  nwords = 0 removes the mask.  The context waits for its streams, re-creates them and probes again which XCDs
- * they reach: on anything but all eight XCDs of an unpartitioned MI355X large host-pointer batches take the row-block
- * pipeline instead of the streaming launch (mcalf_launch_info_t.xcd_mask / .stream_fallback say so).  Results never
- * depend on the mask. */
+ * multi-XCD device consecutive bits go round the XCDs: bit i = CU i / 8 of XCD i % 8) -- as an embedding application does to
+ * share one GPU between ranks.  nwords = 0 removes the mask.  The context waits for its streams, re-creates them and probes
+ * again which XCDs they reach: on anything but all eight XCDs of an unpartitioned MI355X large host-pointer batches take the
+ * row-block pipeline instead of the streaming launch (mcalf_launch_info_t.xcd_mask / .stream_fallback say so).  Measured on
+ * ROCm 7.2 / MI355X (tools/explore/cu_mask_probe.py): an XCD whose share of the mask is EMPTY runs unrestricted, so a mask
+ * slows a stream down but cannot take an XCD away from it -- what does is a partition mode (DPX / QPX / CPX).  Results
+ * never depend on the mask. */
 int mcalf_set_cu_mask(mcalf_ctx* ctx, const uint32_t* mask, int32_t nwords);
 
 /* How a streaming launch deals the rows of a batch to `nxcd` XCDs (blocks of eight rows, block k -> XCD k % nxcd): for

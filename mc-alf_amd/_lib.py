@@ -86,6 +86,8 @@ class mcalf_launch_info_t(C.Structure):
         ("stream_setup_wgs", C.c_int32),
         ("stream_polled", C.c_int32),
         ("xcd_mask", C.c_int32),
+        ("stream_wgs_min", C.c_int32),
+        ("stream_wgs_max", C.c_int32),
         ("stream_fallback", C.c_int32),
     ]
 

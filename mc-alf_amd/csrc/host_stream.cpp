@@ -203,7 +203,7 @@ int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
     const bool trace = ctx->stream_trace;
     double tm[7] = {};
     if (trace) tm[0] = now_us();
-    ctx->last.stream_fallback = 0;
+    ctx->last.stream_fallback = 0; ctx->last.stream_wgs_min = ctx->last.stream_wgs_max = 0;
     if (!ctx->stream_on || ctx->chunks_req > 0 || ctx->host_plan_n > 0 || ctx->profiling || !stream_qualifies(ctx, batch)) return MCALF_OK;
     if (ctx->stream_on == 1 && ctx->ntiles > 1) return MCALF_OK;
     if (ctx->xcd_mask != (1u << kXcds) - 1u) {            // not the device shape the launch deals its rows for: see stream_probe_xcds
@@ -286,7 +286,14 @@ int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
     // Not an answer, although the grid has drained: a wave ran out of patience (h_ctl[0]), or an XCD received no workgroup
     // of the launch (h_ctl[2], the fewest arrivals: every XCD is dealt rows at the sizes that stream, and only its own
     // workgroups evaluate them -- the probe said eight XCDs, this launch met fewer).  The caller goes the pipelined way.
-    const unsigned int gave_up = ctx->h_ctl[0], fewest = ctx->h_ctl[2];
+    const unsigned int gave_up = ctx->h_ctl[0];
+    unsigned int fewest = ctx->h_ctl[2];
+#ifdef MCALF_TESTING
+    // (test builds only: pretend the kernel reported an XCD without workgroups -- no CU mask can produce one on an
+    // unpartitioned device, see mcalf_set_cu_mask -- so that the path behind the report runs in a test)
+    if (const char* t = std::getenv("MCALF_TEST_STARVE")) { if (std::atoi(t) != 0) fewest = 0u; }
+#endif
+    ctx->last.stream_wgs_min = (int32_t)fewest; ctx->last.stream_wgs_max = (int32_t)ctx->h_ctl[3];
     if (gave_up != 0u || fewest == 0u) {
         (void)hipStreamSynchronize(ctx->stream);
         HIP_TRY(ctx, hipMemset(ctx->d_sctl, 0, sizeof(StreamCtl)));

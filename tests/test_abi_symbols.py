@@ -39,7 +39,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.mcalf_spec) == 8 + 3 * 8 + 8 + 8 + 8 + 24 + 4 * 4 + 3 * 8 + 2 * 4 + 8 + 2 * 8
     assert C.sizeof(_lib.mcalf_info_t) == 8 * 4 + 8 + 32
     assert C.sizeof(_lib.mcalf_broker_t) == 2 * 4 + 10 * 8
-    assert C.sizeof(_lib.mcalf_launch_info_t) == 4 * 4 + 8 + 10 * 4 == 64
+    assert C.sizeof(_lib.mcalf_launch_info_t) == 4 * 4 + 8 + 12 * 4 == 72
 
 
 def test_no_cpu_fallback_without_gpu():

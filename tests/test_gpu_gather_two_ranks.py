@@ -148,6 +148,11 @@ def test_bench_n2_times_the_three_gathers_in_one_process_group(fake_rccl):
         assert isinstance(g, dict), (name, g)
         assert g["gather_check"] == {"rows": 4608, "own_block_equal": True, "all_finite": True}, name
         assert g["ms_per_step"] > 0 and 0 < g["kernel_ms_min_over_ranks"] <= g["kernel_ms_max_over_ranks"]
+        # the library's legs count their ranks through the library's own communicator
+        assert (g["rccl_ranks"], g["rccl_ranks_source"]) == (2, "torch.distributed.get_world_size" if name == "torch" else "mcalf_comm_info")
+        sp = g["rank0_split"]
+        assert sp["kernels_ms"] > 0 and sp["exchange_ms"] >= 0 and sp["join_ms"] >= 0
+        assert sp["step_ms_synchronous"] == pytest.approx(sp["kernels_ms"] + sp["exchange_ms"] + sp["join_ms"])
     best = min(out["gathers"], key=lambda k: out["gathers"][k]["ms_per_step"])
     assert out["gather_reported"] == best and out["ms_per_step"] == pytest.approx(out["gathers"][best]["ms_per_step"])
     assert out["value"] == pytest.approx(out["gathers"][best]["value"])

@@ -189,4 +189,11 @@ def test_two_rank_job_through_the_product_path_on_one_gpu():
     g = out["gathers"]["torch"]
     assert g["gather_check"] == out["gather_check"] and g["ms_per_step"] == pytest.approx(out["ms_per_step"])
     assert 0 < g["kernel_ms_min_over_ranks"] <= g["kernel_ms_max_over_ranks"]
+    # what the first real multi-GPU run will be read by: per-leg rank count and its source, the ranks' kernel times, and
+    # where rank 0's (synchronous) step goes
+    assert (g["rccl_ranks"], g["rccl_ranks_source"]) == (2, "torch.distributed.get_world_size")
+    sp = g["rank0_split"]
+    assert set(sp) >= {"steps", "kernels_ms", "exchange_ms", "join_ms", "step_ms_synchronous", "how"}
+    assert sp["kernels_ms"] > 0 and sp["exchange_ms"] >= 0 and sp["join_ms"] >= 0
+    assert sp["step_ms_synchronous"] == pytest.approx(sp["kernels_ms"] + sp["exchange_ms"] + sp["join_ms"])
     assert all(isinstance(out["gathers"][k], str) and out["gathers"][k].startswith("skipped") for k in ("inlib", "inlib_overlap"))

@@ -71,9 +71,12 @@ def test_a_larger_batch_after_exactly_one_streamed_call_is_not_answered_by_the_o
 
 
 def test_cu_masked_context_gives_the_same_bits_and_never_streams_onto_xcds_it_cannot_reach():
-    """The context's own stream restricted to the compute units of ONE XCD, then of four (`mcalf_set_cu_mask`, as an
-    application that shares a GPU between ranks does): the probe sees fewer than eight XCDs, the host entry takes the
-    row-block pipeline (`stream_fallback` = SHAPE) and returns the device entry's bits; without the mask it streams again."""
+    """The context's own stream restricted by CU masks (`mcalf_set_cu_mask`, as an application that shares a GPU between
+    ranks does): every eighth CU (all of one XCD's in the runtime's numbering), those of four XCDs, the first 32 bits.
+    Whatever the probe then sees decides the path -- fewer than eight XCDs: the row-block pipeline (`stream_fallback` =
+    SHAPE); eight: the streaming launch (measured on ROCm 7.2 / MI355X: an XCD whose share of a mask is empty runs
+    unrestricted, so a mask cannot take an XCD away; tools/explore/cu_mask_probe.py) -- and the bits are the device
+    entry's either way; without the mask it streams again."""
     kw, _, seed = workloads.config("C", oracle_synth)
     n = 2600
     P = workloads.draw_P(kw, n, np.random.default_rng(seed + 99))
@@ -82,9 +85,10 @@ def test_cu_masked_context_gives_the_same_bits_and_never_streams_onto_xcds_it_ca
         assert np.array_equal(fit.loglike_batch(P), want)
         ll = fit.last_launch()
         assert (ll.path, ll.xcd_mask, ll.stream_fallback) == (STREAM, 0xFF, 0)
-        for xcds in ({0}, {1, 3, 5, 7}):
+        for xcds in ({0}, {1, 3, 5, 7}, None):
+            words = _xcd_words(xcds) if xcds else np.array([0xFFFFFFFF] + [0] * 7, dtype=np.uint32)
             try:
-                fit.set_cu_mask(_xcd_words(xcds))
+                fit.set_cu_mask(words)
             except RuntimeError as exc:
                 pytest.skip(f"this runtime refuses CU-masked streams: {exc}")
             got = fit.loglike_batch(P[::-1].copy())[::-1]
@@ -95,7 +99,9 @@ def test_cu_masked_context_gives_the_same_bits_and_never_streams_onto_xcds_it_ca
             assert seen, "the probe saw no workgroup at all"
             if ll.xcd_mask != 0xFF:                           # (the mask did confine the stream: then it must not stream)
                 assert (ll.path, ll.stream_fallback) == (PIPELINED, _lib.MCALF_STREAM_FALLBACK_SHAPE), xcds
-                assert seen == xcds, (seen, xcds)             # consecutive CU-mask bits go round the XCDs
+                assert xcds is None or seen == xcds, (seen, xcds)     # consecutive CU-mask bits go round the XCDs
+            else:
+                assert (ll.path, ll.stream_fallback) == (STREAM, 0) and ll.stream_wgs_min >= 1
             assert np.array_equal(fit.chi2_batch(P), fit.chi2_batch(P[::-1].copy())[::-1])
             # small calls and model output are not affected
             assert np.array_equal(fit.loglike_batch(P[:5]), want[:5])
@@ -107,43 +113,41 @@ def test_cu_masked_context_gives_the_same_bits_and_never_streams_onto_xcds_it_ca
             fit.set_cu_mask(np.zeros(8, dtype=np.uint32))
 
 
-def _worker(tmp_path, lib, forced, *extra):
-    out = os.path.join(str(tmp_path), "res_%s_%s.json" % (forced, "_".join(extra)))
+def _worker(tmp_path, lib, env_extra, *extra):
+    tag = "_".join("%s%s" % kv for kv in sorted(env_extra.items())) + "_".join(extra)
+    out = os.path.join(str(tmp_path), "res_%s.json" % tag.replace("MCALF_TEST_", ""))
     env = dict(os.environ, MCALF_HIP_LIB=lib, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if forced is None:
-        env.pop("MCALF_TEST_XCD_MASK", None)
-    else:
-        env["MCALF_TEST_XCD_MASK"] = forced
+    for k in ("MCALF_TEST_XCD_MASK", "MCALF_TEST_STARVE"):
+        env.pop(k, None)
+    env.update(env_extra)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "stream_shape_worker.py"), out, "2600", *extra],
                          env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     return json.load(open(out))
 
 
-def test_a_launch_that_meets_fewer_xcds_than_the_probe_promised_is_discarded(tmp_path, testing_lib):
-    """The check BEHIND every streaming launch.  The test variant of the library is told to believe that its stream reaches
-    all eight XCDs (MCALF_TEST_XCD_MASK=0xFF) while the stream is confined to the compute units of XCD 0: the launch
-    runs, seven XCDs receive no workgroup, their rows are never evaluated -- the arrival counts say so, the results are
-    discarded and the row-block pipeline answers with the device entry's bits (`stream_fallback` = STARVED); the context
-    does not try again.  Control runs: the same library without the override streams; told that only four XCDs exist it
-    does not launch the stream at all (SHAPE)."""
-    ok = _worker(tmp_path, testing_lib, None)
+def test_a_launch_that_reports_an_xcd_without_workgroups_is_discarded(tmp_path, testing_lib):
+    """The check BEHIND every streaming launch: the kernel counts the workgroups every XCD received, and a launch in which
+    an XCD that was dealt rows got none is not an answer.  On the unpartitioned device of a test box no stream can be
+    made to miss an XCD (see above), so the TEST variant of the library (a) is told that its stream reaches four XCDs
+    only (MCALF_TEST_XCD_MASK=0x0F: no streaming launch is attempted, `stream_fallback` = SHAPE) and (b) is made to read
+    the kernel's report as "an XCD got nothing" (MCALF_TEST_STARVE=1): the launch's results are discarded, the
+    row-block pipeline answers with the device entry's bits (STARVED), and the context does not stream again.  The
+    control run of the same library streams, and its kernel reports every XCD served."""
+    ok = _worker(tmp_path, testing_lib, {})
     assert ok["finite"] and [c["path"] for c in ok["calls"]] == [STREAM, STREAM]
     assert all(c["equal"] and c["fallback"] == 0 and c["xcd_mask"] == 0xFF for c in ok["calls"])
-    four = _worker(tmp_path, testing_lib, "0x0F")
+    assert all(1 <= c["wgs_min"] <= c["wgs_max"] <= 512 for c in ok["calls"])        # counted by the kernel: every XCD was there
+    four = _worker(tmp_path, testing_lib, {"MCALF_TEST_XCD_MASK": "0x0F"})
     assert [(c["path"], c["fallback"], c["xcd_mask"], c["equal"]) for c in four["calls"]] == \
         [(PIPELINED, _lib.MCALF_STREAM_FALLBACK_SHAPE, 0x0F, True)] * 2
-    real = _worker(tmp_path, testing_lib, None, "xcd0")        # what the mask really does to the stream, unforced
-    if real["cu_mask"] != "set":
-        pytest.skip("this runtime refuses CU-masked streams: " + real["cu_mask"])
-    assert all(c["equal"] for c in real["calls"])
-    if real["calls"][0]["xcd_mask"] == 0xFF:
-        pytest.skip("a CU mask of every eighth CU does not confine a stream to one XCD on this runtime")
-    assert [(c["path"], c["fallback"]) for c in real["calls"]] == [(PIPELINED, _lib.MCALF_STREAM_FALLBACK_SHAPE)] * 2
-    lied = _worker(tmp_path, testing_lib, "0xFF", "xcd0")
-    first, second = lied["calls"]
+    starved = _worker(tmp_path, testing_lib, {"MCALF_TEST_STARVE": "1"})
+    first, second = starved["calls"]
     assert first["equal"] and second["equal"]                  # right bits whatever happened underneath
-    assert first["path"] == PIPELINED
-    assert first["fallback"] == _lib.MCALF_STREAM_FALLBACK_STARVED, lied     # launched, found starved, discarded
-    assert first["xcd_mask"] == 0                               # ... and what the probe "said" is no longer believed
+    assert (first["path"], first["fallback"]) == (PIPELINED, _lib.MCALF_STREAM_FALLBACK_STARVED), starved
+    assert first["wgs_min"] == 0 and first["xcd_mask"] == 0     # ... and what the probe said is no longer believed:
     assert (second["path"], second["fallback"]) == (PIPELINED, _lib.MCALF_STREAM_FALLBACK_SHAPE)
+    # one compute unit per XCD (the smallest mask that leaves every XCD one): streams, eight XCDs, same bits
+    few = _worker(tmp_path, testing_lib, {}, "cus8")
+    if few["cu_mask"] == "set":
+        assert all(c["equal"] and c["path"] == STREAM and c["xcd_mask"] == 0xFF and c["wgs_min"] >= 1 for c in few["calls"]), few
