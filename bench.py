@@ -693,7 +693,7 @@ def main():
         }
         if pmc:
             out["roofline_valu"].update({k: pmc[k] for k in ("valu_busy", "executed_flops_per_launch", "executed_flops_note",
-                                                             "valu_active_lane_fraction", "executed_flops_lane_weighted_estimate",
+                                                             "valu_active_lane_fraction", "valu_active_lane_fraction_note", "executed_flops_lane_weighted_estimate",
                                                              "source") if k in pmc})
             if "executed_flops_per_launch" in pmc:
                 ex = pmc["executed_flops_per_launch"] / (kern_ms * 1e-3) / 1e12

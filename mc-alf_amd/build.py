@@ -105,6 +105,54 @@ def build(force: bool = False, verbose: bool = False, testing: bool = False, tar
     return target
 
 
+def build_tree(workdir: str, target: str, stamp: str = "patched-copy", defines=(), kernel_flags=(), report: bool = False) -> str:
+    """Compile a COPY of the sources (tools/make_acc_build.py and friends patch one: the product source carries no
+    instrumentation) into `target`; with `report` the kernels' resource usage is returned instead of the path."""
+    hipcc = _hipcc()
+    objs = []
+    log = ""
+    for src in SOURCES:
+        obj = os.path.splitext(src)[0] + ".o"
+        if src == KERNEL_SOURCE:
+            cmd = [hipcc] + KERNEL_FLAGS + list(kernel_flags) + (["-Rpass-analysis=kernel-resource-usage"] if report else [])
+        else:
+            cmd = [hipcc] + HOST_FLAGS + [f'-DMCALF_SRC_HASH="{stamp}"']
+        res = subprocess.run(cmd + [f"-D{d}" for d in defines] + ["-c", src, "-o", obj], cwd=workdir, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, res.stderr[-4000:]))
+        if src == KERNEL_SOURCE:
+            log = res.stderr
+        objs.append(obj)
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs + ["-ldl"], cwd=workdir,
+                         capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("link failed:\n" + res.stderr[-4000:])
+    return log if report else target
+
+
+def copy_sources(workdir: str) -> None:
+    """A copy of everything the library is built from, laid out so that the copies' includes resolve inside `workdir`."""
+    os.makedirs(os.path.join(workdir, "include"), exist_ok=True)
+    for f in os.listdir(CSRC):
+        if f.endswith((".h", ".hip", ".cpp")):
+            shutil.copy(os.path.join(CSRC, f), workdir)
+    shutil.copy(os.path.join(CSRC, "..", "..", "include", "mcalf_hip.h"), os.path.join(workdir, "include"))
+    hp = os.path.join(workdir, "host_ctx.h")
+    txt = open(hp).read().replace('#include "../../include/mcalf_hip.h"', '#include "include/mcalf_hip.h"')
+    open(hp, "w").write(txt)
+
+
+def resource_table(log: str, only: str = "fused"):
+    """(kernel, VGPRs, scratch bytes per lane, occupancy, SGPR spills, VGPR spills) from a -Rpass-analysis log."""
+    import re
+    rows = []
+    for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)"
+                         r".*?SGPRs Spill: (\d+).*?VGPRs Spill: (\d+)", log, re.S):
+        if only in m.group(1):
+            rows.append((m.group(1),) + tuple(int(m.group(k)) for k in range(2, 7)))
+    return rows
+
+
 if __name__ == "__main__":
     import sys
     if "--hash" in sys.argv:                  # (the Makefile stamps the library with it)

@@ -35,19 +35,22 @@ args = ap.parse_args()
 if os.environ.get("MCALF_COUNT_INTERP"):
     args.count_interp = True
 
-os.makedirs(os.path.join(work, "include"), exist_ok=True)
 os.makedirs(os.path.join(root, "build", "abl"), exist_ok=True)
-for f in ("voigt_device.h", "voigt_tables.h"):
-    shutil.copy(os.path.join(src, f), work)
-shutil.copy(os.path.join(root, "include", "mcalf_hip.h"), os.path.join(work, "include"))
-s = open(os.path.join(src, "mcalf_hip.hip")).read().replace('"../../include/mcalf_hip.h"', '"include/mcalf_hip.h"')
+sys.path.insert(0, root)
+import importlib  # noqa: E402
+bld = importlib.import_module("mc-alf_amd.build")
+bld.copy_sources(work)
+FILES = ["kernels.hip", "kernel_args.h", "host_abi.cpp"]
+text = {f: open(os.path.join(work, f)).read() for f in FILES}
 
 
 def rep(a, b, count=1):
-    global s
-    if s.count(a) != count:
-        sys.exit("make_acc_build: expected %d occurrence(s), found %d, of:\n%s" % (count, s.count(a), a))
-    s = s.replace(a, b)
+    """Replace the hook `a` in whichever source file carries it (exactly `count` occurrences over all of them)."""
+    found = sum(text[f].count(a) for f in FILES)
+    if found != count:
+        sys.exit("make_acc_build: expected %d occurrence(s), found %d, of:\n%s" % (count, found, a))
+    for f in FILES:
+        text[f] = text[f].replace(a, b)
 
 
 STAMP = ("do { if (threadIdx.x == 0 && w < 8192) g_stamps[w * 8 + (%d)] = %s; } while (0);")
@@ -62,14 +65,14 @@ if not args.no_stamps or args.count_interp:
         "__device__ unsigned long long g_stamps[8192 * 8];\n__device__ unsigned long long g_dbg[4];   // [0] interpolated segments, "
         "[1] segments seen, [2] interpolable\n__device__ unsigned long long g_acc[8192 * 32];\n#define CLK() __builtin_amdgcn_s_memtime()\n"
         "// acc += a * b and acc += a with the accumulator tied to its register")
-    rep('extern "C" int mcalf_voigt_hjerting(',
+    rep('// ---- kernel entry points for the host files (kernel_args.h) -------------------------------------------------------------',
         'extern "C" int mcalf_diag_read_stamps(unsigned long long* out, int n) {\n'
         '    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_stamps), (size_t)n * sizeof(unsigned long long));\n}\n'
         'extern "C" int mcalf_diag_read_dbg(unsigned long long* out) {\n'
         '    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_dbg), 4 * sizeof(unsigned long long));\n}\n'
         'extern "C" int mcalf_diag_read_acc(unsigned long long* out, int n) {\n'
         '    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mcalf::g_acc), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;\n}\n'
-        'extern "C" int mcalf_voigt_hjerting(')
+        '// ---- kernel entry points for the host files (kernel_args.h) -------------------------------------------------------------')
 
 if args.count_interp:
     rep("        done = uniform64((mp | mn) & segOk);                 // (segOk carries bits 8j only, so `done` does too)\n",
@@ -122,7 +125,8 @@ if args.abl_setup & 1:
 if args.no_far_interp:
     rep("constexpr bool kFarInterp = true;", "constexpr bool kFarInterp = false;")
 
-open(os.path.join(work, "acc.hip"), "w").write(s)
+for f in FILES:
+    open(os.path.join(work, f), "w").write(text[f])
 out = os.path.join(root, "build", "abl", args.name + ".so")
-subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", out, "acc.hip"], cwd=work)
+bld.build_tree(work, out, stamp="instrumented:" + args.name)
 print("built", out)

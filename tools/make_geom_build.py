@@ -25,19 +25,22 @@ ap.add_argument("--waves", type=int, default=5, help="waves per SIMD the kernel 
 ap.add_argument("--cf-lds", action="store_true")
 ap.add_argument("--report", action="store_true", help="print the kernels' register usage")
 args = ap.parse_args()
-os.makedirs(os.path.join(work, "include"), exist_ok=True)
 os.makedirs(os.path.join(root, "build", "abl"), exist_ok=True)
-for f in ("voigt_device.h", "voigt_tables.h"):
-    shutil.copy(os.path.join(src, f), work)
-shutil.copy(os.path.join(root, "include", "mcalf_hip.h"), os.path.join(work, "include"))
-s = open(os.path.join(src, "mcalf_hip.hip")).read().replace('"../../include/mcalf_hip.h"', '"include/mcalf_hip.h"')
+sys.path.insert(0, root)
+import importlib  # noqa: E402
+bld = importlib.import_module("mc-alf_amd.build")
+bld.copy_sources(work)
+FILES = ["kernels.hip", "kernel_args.h", "host_abi.cpp"]
+text = {f: open(os.path.join(work, f)).read() for f in FILES}
 
 
 def rep(a, b, count=1):
-    global s
-    if s.count(a) != count:
-        sys.exit("make_geom_build: expected %d occurrence(s), found %d, of:\n%s" % (count, s.count(a), a))
-    s = s.replace(a, b)
+    """Replace the hook `a` in whichever source file carries it (exactly `count` occurrences over all of them)."""
+    found = sum(text[f].count(a) for f in FILES)
+    if found != count:
+        sys.exit("make_geom_build: expected %d occurrence(s), found %d, of:\n%s" % (count, found, a))
+    for f in FILES:
+        text[f] = text[f].replace(a, b)
 
 
 rep("constexpr int kBlock = 512;", "constexpr int kBlock = %d;" % args.threads)
@@ -45,7 +48,7 @@ rep("constexpr int kPpt = 8;  ", "constexpr int kPpt = %d;  " % args.ppt)
 rep("constexpr int kExtMax = kBlock * kPpt;", "constexpr int kThreadPix = kBlock * kPpt;\nconstexpr int kExtMax = 4096;")
 rep('static_assert(kBlock == 64 * VT_INODES, "one interpolation weight per thread");\n', "")
 rep('static_assert(kPpt == 8, "the skip tests of eval_line treat the eight segments of a wave as two halves");\n', "")
-rep("constexpr int kMinWaves = 4; ", "constexpr int kMinWaves = %d; " % args.waves)
+rep("constexpr int kMinWaves = 4;  ", "constexpr int kMinWaves = %d;  " % args.waves)
 rep("    if (kFarInterp) sWt[(tid0 & 7) * 64 + (tid0 >> 3)] = a.wtab[tid0];", "    if (kFarInterp && tid0 < 64 * VT_INODES) sWt[(tid0 & 7) * 64 + (tid0 >> 3)] = a.wtab[tid0];")
 rep("""    for (int h = 0; h < kPpt / 4; ++h) {
     const unsigned dh = h ? doneHi : doneLo;
@@ -78,25 +81,19 @@ rep("""            for (int jj = 0; jj < 2; ++jj) {
                 if (j >= kPpt) break;
                 if (selfHalo) {""")
 rep("            if (r >= a.nrows) continue;\n", "            if (r >= a.nrows || wave >= 8) continue;\n")
-rep("        if (lane < cnt) {\n            const int r = stream_row(x, 8 * (c + lane) + wave);\n            if (r < a.nrows)",
-    "        if (lane < cnt && wave < 8) {\n            const int r = stream_row(x, 8 * (c + lane) + wave);\n            if (r < a.nrows)")
+rep("        if (lane < cnt) {\n            const int r = stream_row(x, 8 * (c + lane) + wave, nx);\n            if (r < a.nrows)",
+    "        if (lane < cnt && wave < 8) {\n            const int r = stream_row(x, 8 * (c + lane) + wave, nx);\n            if (r < a.nrows)")
 rep("    const long nu_len = ctx->selfhalo ? (long)kExtMax : ctx->npix;", "    const long nu_len = ctx->selfhalo ? (long)kThreadPix : ctx->npix;")
 if args.cf_lds:
     rep("""    double cF[VT_FDEG + 1];
 #pragma unroll
     for (int k = 0; k <= VT_FDEG; ++k) cF[k] = tab[kZFLds + k];
 """, "    const double* cF = tab + kZFLds;       // (read where they are used: 14 registers fewer across the line)\n")
-open(os.path.join(work, "geom.hip"), "w").write(s)
+for f in FILES:
+    open(os.path.join(work, f), "w").write(text[f])
 out = os.path.join(root, "build", "abl", "geom_%dx%d%s.so" % (args.threads, args.ppt, "_cflds" if args.cf_lds else ""))
-cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", out, "geom.hip"]
+log = bld.build_tree(work, out, stamp="geometry_experiment", report=True)
 if args.report:
-    cmd.append("-Rpass-analysis=kernel-resource-usage")
-res = subprocess.run(cmd, cwd=work, capture_output=True, text=True)
-if res.returncode:
-    sys.exit(res.stderr[-3000:])
-if args.report:
-    import re
-    for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+).*?SGPRs Spill: (\d+).*?VGPRs Spill: (\d+)", res.stderr, re.S):
-        if "fused" in m.group(1):
-            print(m.group(1)[-32:], "VGPR", m.group(2), "scratch", m.group(3), "occupancy", m.group(4), "sgpr-spill", m.group(5), "vgpr-spill", m.group(6))
+    for row in bld.resource_table(log):
+        print("%-34s VGPR %3d scratch %3d occupancy %d sgpr-spill %3d vgpr-spill %3d" % ((row[0][-34:],) + row[1:]))
 print("built", out)

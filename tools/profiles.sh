@@ -3,8 +3,8 @@
 # command (one fused launch per step), the PMC passes (each --pmc set its own run, no trace domains), the
 # instruction-issue micro-benchmark; then the figures are merged into profiles/pmc.json / traffic.json (stamped with the
 # kernel-source hash) and the bench line is taken AGAIN, now carrying them (bench_with_counters.json).
-# Usage: tools/profiles.sh <config> <outdir> [steps] [round tag, default r04]
-cfg=${1:-C}; out=${2:-gpurun_out/prof_$cfg}; steps=${3:-50}; tag=${4:-r04}
+# Usage: tools/profiles.sh <config> <outdir> [steps] [round tag, default r05]
+cfg=${1:-C}; out=${2:-gpurun_out/prof_$cfg}; steps=${3:-50}; tag=${4:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
 timeout -k 10 600 python bench.py --config $cfg --steps $steps > "$out/bench.json" 2> "$out/bench.err" || echo "bench failed"
@@ -22,6 +22,10 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
 done
 [ -x build/issue_rate ] || hipcc -O3 --offload-arch=gfx950 -o build/issue_rate tools/micro/issue_rate.hip 2>/dev/null
 [ -x build/issue_rate ] && timeout -k 10 120 build/issue_rate > "$out/issue_rate.json" 2> "$out/issue_rate.err"
+# (the unit of SQ_THREAD_CYCLES_VALU, measured on the same lease: kernels with a known share of active lanes)
+[ -x build/lane_unit ] || hipcc -O3 --offload-arch=gfx950 -o build/lane_unit tools/micro/lane_unit.hip 2>/dev/null
+[ -x build/lane_unit ] && timeout -k 10 200 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU -d "$out/lane_unit" --output-format csv -- build/lane_unit > "$out/lane_unit.log" 2>&1 \
+  && python3 tools/micro/lane_unit_summary.py "$out/lane_unit" "$out/lane_unit.json" > "$out/lane_unit.txt"
 python3 tools/profiles_summary.py "$cfg" "$out"
 python3 tools/collect_profiles.py --round $tag --src "$out" $cfg
 timeout -k 10 600 python bench.py --config $cfg --steps $steps > "$out/bench_with_counters.json" 2> "$out/bench_with_counters.err" || echo "second bench failed"

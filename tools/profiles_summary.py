@@ -43,11 +43,24 @@ if g("SQ_INSTS_VALU_FMA_F64") is not None:
     res["executed_flops_per_launch"] = 64.0 * (f64 + g("SQ_INSTS_VALU_FMA_F64"))
     res["executed_flops_note"] = ("64 lanes x (2 FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) wave instructions: an UPPER BOUND -- exec masks "
                                   "are ignored (a wave instruction counts 64 lanes whether 1 or 64 of them are enabled)")
-    if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
-        # thread-cycles of VALU work over (busy quad-cycles x 4 cycles x 64 lanes): the share of lanes enabled while the
-        # vector pipe was busy, over ALL vector instructions (not only the FP64 ones)
-        lane = g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 4.0 * 64.0)
+    if g("SQ_THREAD_CYCLES_VALU") and g("SQ_INSTS_VALU"):
+        # Share of lanes enabled over ALL vector instructions (not only the FP64 ones).  SQ_THREAD_CYCLES_VALU adds, per
+        # vector instruction, (its enabled lanes) x (a per-instruction unit): the unit is MEASURED on the same lease with
+        # kernels whose lane share is known (tools/micro/lane_unit.hip: 64 of 64 lanes and 16 of 64 in an FP64 FMA loop) --
+        # round 4 divided by SQ_ACTIVE_INST_VALU x 4 x 64 instead, a factor of four too much (0.22 where 0.89 was meant).
+        unit, how = 1.0, "unit 1 per instruction assumed (no lane_unit.json in this run)"
+        try:
+            cal = json.load(open(out + "/lane_unit.json"))
+            full = cal["lanes64_f64"]["thread_cycles_over_insts_x64"]
+            part = cal["lanes16_f64"]["thread_cycles_over_insts_x64"]
+            unit = full
+            how = ("unit %.3f per instruction: tools/micro/lane_unit.hip on the same lease gives THREAD_CYCLES / (INSTS x 64) = %.3f with "
+                   "64 of 64 lanes enabled and %.3f with 16 of 64 (FP64 FMA loops)" % (full, full, part))
+        except (OSError, ValueError, KeyError):
+            pass
+        lane = g("SQ_THREAD_CYCLES_VALU") / (g("SQ_INSTS_VALU") * 64.0 * unit)
         res["valu_active_lane_fraction"] = lane
+        res["valu_active_lane_fraction_note"] = "SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64 lanes x unit); " + how
         res["executed_flops_lane_weighted_estimate"] = res["executed_flops_per_launch"] * min(lane, 1.0)
 if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
     res["fetch_size_kib_raw"], res["write_size_kib"] = g("FETCH_SIZE"), g("WRITE_SIZE")
