@@ -69,7 +69,7 @@ extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     if (ctx->d_res_shared) (void)hipFree(ctx->d_res_shared);
     void* bufs[] = {ctx->d_nu, ctx->d_obj, ctx->d_ispec2, ctx->d_lgis, ctx->d_err, ctx->d_tabs, ctx->d_lines, ctx->d_wtab, ctx->d_segok,
                     ctx->d_P,  ctx->d_out, ctx->d_partial, ctx->d_model, ctx->d_bounds, ctx->d_prior, ctx->d_recs, ctx->d_taps, ctx->d_hdr,
-                    ctx->d_queue, ctx->d_order, ctx->d_sws};
+                    ctx->d_queue, ctx->d_order, ctx->d_sws, ctx->d_wide, ctx->d_wtaps, ctx->d_wpartial, ctx->d_wrows, ctx->d_whdr};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_ctl) (void)hipHostFree((void*)ctx->h_ctl);
@@ -156,13 +156,24 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         const int v = std::atoi(e);
         if (v == 4 || (v == 5 && ext_for(5) == ext_for(4))) ctx->lps = v;
     }
+    if (ext_for(ctx->lps) < 2 * (size_t)ctx->n_cap + 64) {
+        // The LSF does not fit a workgroup tile with its halo.  numpy boundary: the fused kernel then runs without
+        // convolution (a tile without halo) and the wide kernels convolve from HBM (launch_wide) -- the reference simply
+        // builds a longer kernel (hires_fitter.py:458-464).  JAX semantics keep their fixed grid inside the tile.
+        if (ctx->conv_mode != MCALF_CONV_WRAP_NUMPY || 2.0 * (double)ctx->n_cap + 1.0 > 6.0e7)
+            return set_err(ctx, MCALF_ERR_RANGE,
+                           "LSF half-width %d px (specres_max %.3g km/s at %.3g km/s/px) with %d component-lines does not "
+                           "fit a %d-pixel workgroup tile / the %zu-byte LDS budget", ctx->n_cap, rmax, sp->velstep,
+                           ctx->ncl_cap, kExtMax, kLdsBudget);
+        ctx->wide = 1;
+        ctx->wide_n_cap = ctx->n_cap;
+        ctx->n_cap = 0;
+        ctx->lps = ((ctx->ncl_cap + 4) / 5 < (ctx->ncl_cap + 3) / 4 && ext_for(5) == ext_for(4)) ? 5 : 4;
+    }
     const size_t fixed_doubles = fixed_for(ctx->lps);
     size_t ext = ext_for(ctx->lps);
     if (ext < 2 * (size_t)ctx->n_cap + 64)
-        return set_err(ctx, MCALF_ERR_RANGE,
-                       "LSF half-width %d px (specres_max %.3g km/s at %.3g km/s/px) with %d component-lines does not "
-                       "fit a %d-pixel workgroup tile / the %zu-byte LDS budget", ctx->n_cap, rmax, sp->velstep,
-                       ctx->ncl_cap, kExtMax, kLdsBudget);
+        return set_err(ctx, MCALF_ERR_RANGE, "%d component-lines do not fit the %zu-byte LDS budget", ctx->ncl_cap, kLdsBudget);
     // tiles are multiples of 8 pixels (the epilogue works in aligned groups of 8), balanced over the spectrum
     const long tmax = ((long)ext - 2 * ctx->n_cap) & ~7L;
     long tile = std::min(tmax, (ctx->npix + 7) & ~7L);
@@ -361,7 +372,7 @@ extern "C" int mcalf_info(const mcalf_ctx* ctx, mcalf_info_t* info) {
     info->ndim = ctx->ndim;
     info->startind = ctx->startind;
     info->endind = ctx->endind;
-    info->n_cap = ctx->n_cap;
+    info->n_cap = ctx->wide ? ctx->wide_n_cap : ctx->n_cap;      // (what specres_max provisions, wherever the convolution runs)
     info->tile = ctx->tile;
     info->ntiles = ctx->ntiles;
     info->device = ctx->device;
@@ -466,6 +477,13 @@ KArgs make_kargs(const mcalf_ctx* ctx, int mode, const double* dP, int64_t row0,
     a.nitems = (int)(nrows * ctx->ntiles);
     a.nrows = (int)nrows;
     a.queue = ctx->d_queue + chunk;
+    if (ctx->wide_stage1) {
+        // the convolution-free fused launch of a wide-LSF context: no resolution exceeds this step (hires_fitter.py:445), the
+        // continuum is 1 -- the wide kernels apply both afterwards (the layout fields startind / endind stay the context's)
+        a.velstep = 1e300; a.freecont = 0; a.contval_fixed = 1.0;
+    } else if (ctx->wide) {
+        a.n_cap = ctx->wide_n_cap;                        // (arguments of the wide kernels)
+    }
     return a;
 }
 
@@ -576,10 +594,80 @@ int launch_preflight(mcalf_ctx* ctx, int mode, int64_t batch) {
     return grow_sample_ws(ctx, batch);
 }
 
+// A batch of a WIDE-LSF context (ctx->wide: the LSF half-width does not fit a workgroup tile; numpy boundary): per pass of
+// at most `rows` live points -- bounded scratch -- (1) the fused kernel WITHOUT convolution and continuum (make_kargs:
+// wide_stage1) writes the unconvolved spectra into d_wide, (2) mcalf_wide_taps_kernel forms every live point's taps,
+// (3) mcalf_wide_conv_kernel convolves periodically from HBM, applies the continuum and writes the model rows and / or the
+// block sums of the likelihood terms, (4) mcalf_finalize_kernel adds those up.  Same entry points, same error values
+// (a resolution beyond specres_max: NaN model, logL = -inf, chi2 = +inf); hires_fitter.py:445-464.
+static int launch_wide(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill, double* d_out,
+                       double* d_model, hipStream_t stream, bool from_cube, double* d_theta) {
+    const int64_t npix = ctx->npix, tapw = 2 * (int64_t)ctx->wide_n_cap + 1;
+    const int rowlen = (mode == kModeOneComp) ? 5 : ctx->ndim;
+    const bool reduces = (mode == kModeLogL || mode == kModeChi2);
+    constexpr size_t kScratchBytes = (size_t)512 << 20;           // per buffer and pass
+    const size_t per_row = sizeof(double) * (size_t)std::max(npix, tapw);
+    if (per_row > kScratchBytes) return set_err(ctx, MCALF_ERR_RANGE, "wide LSF: one live point needs %zu bytes of scratch", per_row);
+    const int64_t rows = std::min<int64_t>(batch, std::min<int64_t>(65535, std::max<int64_t>(1, (int64_t)(kScratchBytes / per_row))));
+    const int nblocks = (int)((npix + kWideBlockThreads - 1) / kWideBlockThreads);
+    int rc;
+    if ((rc = launch_preflight(ctx, kModeModel, rows))) return rc;
+    if ((rc = grow(ctx, &ctx->d_wide, &ctx->cap_wide, (size_t)rows * npix))) return rc;
+    if ((rc = grow(ctx, &ctx->d_wtaps, &ctx->cap_wtaps, (size_t)rows * tapw))) return rc;
+    if ((rc = grow(ctx, &ctx->d_whdr, &ctx->cap_whdr, (size_t)rows))) return rc;
+    if (reduces && (rc = grow(ctx, &ctx->d_wpartial, &ctx->cap_wpartial, (size_t)rows * nblocks * 4))) return rc;
+    if (mode == kModeOneComp && (rc = grow(ctx, &ctx->d_wrows, &ctx->cap_wrows, (size_t)rows * 5))) return rc;
+    ctx->last.row_blocks = (int32_t)((batch + rows - 1) / rows);
+    for (int64_t r0 = 0; r0 < batch; r0 += rows) {
+        const int64_t n = std::min(rows, batch - r0);
+        const double* P0 = dP + (size_t)r0 * rowlen;
+        const double* P1 = P0;
+        if (mode == kModeOneComp) {                           // (the fused kernel reads this mode's continuum from the row: rows with 1)
+            double* wr = ctx->d_wrows;
+            long cnt = (long)n;
+            void* kargs[] = {(void*)&P0, (void*)&wr, (void*)&cnt};
+            HIP_TRY(ctx, hipLaunchKernel(wide_rows_kernel_ptr(), dim3((unsigned)((n * 5 + 255) / 256)), dim3(256), kargs, 0, stream));
+            P1 = wr;
+        }
+        ctx->wide_stage1 = true;
+        rc = launch_range(ctx, mode == kModeOneComp ? kModeOneComp : kModeModel, P1, 0, n, 0, targonly, onecomp_fill, nullptr, ctx->d_wide,
+                          stream, from_cube, d_theta ? d_theta + (size_t)r0 * ctx->ndim : nullptr, r0 == 0);
+        ctx->wide_stage1 = false;
+        if (rc) return rc;
+        KArgs a = make_kargs(ctx, mode, P0, 0, n, 0, targonly, onecomp_fill, d_out ? d_out + r0 : nullptr,
+                             d_model ? d_model + (size_t)r0 * npix : nullptr, from_cube, nullptr);
+        a.partial = ctx->d_wpartial;
+        double* taps = ctx->d_wtaps;
+        const double* taps_c = taps;
+        const double* flux = ctx->d_wide;
+        SampleHdr* hdr = ctx->d_whdr;
+        const SampleHdr* hdr_c = hdr;
+        long stride = (long)tapw;
+        int nb = nblocks;
+        {
+            void* kargs[] = {(void*)&a, (void*)&taps, (void*)&stride, (void*)&hdr};
+            HIP_TRY(ctx, hipLaunchKernel(wide_taps_kernel_ptr(), dim3((unsigned)n), dim3(kWideBlockThreads), kargs, 0, stream));
+        }
+        {
+            void* kargs[] = {(void*)&a, (void*)&flux, (void*)&taps_c, (void*)&stride, (void*)&hdr_c, (void*)&nb};
+            HIP_TRY(ctx, hipLaunchKernel(wide_conv_kernel_ptr(), dim3((unsigned)nblocks, (unsigned)n), dim3(kWideBlockThreads), kargs, 0, stream));
+        }
+        if (reduces) {
+            const int keep = ctx->ntiles;
+            ctx->ntiles = nblocks;                             // (launch_finalize adds ntiles partials per live point)
+            rc = launch_finalize(ctx, a, n, mode, stream);
+            ctx->ntiles = keep;
+            if (rc) return rc;
+        }
+    }
+    return MCALF_OK;
+}
+
 int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill,
            double* d_out, double* d_model, hipStream_t stream, bool from_cube, double* d_theta) {
     if (batch == 0) return MCALF_OK;
     int rc;
+    if (ctx->wide) return launch_wide(ctx, mode, dP, batch, targonly, onecomp_fill, d_out, d_model, stream, from_cube, d_theta);
     // MCALF_STREAM_DEVICE=1 (diagnostic): device-pointer batches through the streaming single launch as well -- every
     // row is there from the start, so the whole grid sets up eight live points per workgroup and goes on to the items
     if (ctx->stream_device && (mode == kModeLogL || mode == kModeChi2) && !from_cube && !d_model && ctx->chunks_req <= 1 &&
@@ -837,7 +925,7 @@ static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
     if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, (size_t)batch * rowlen))) return rc;
     if (out_scalar && (rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
     if (out_model && (rc = grow(ctx, &ctx->d_model, &ctx->cap_model, (size_t)batch * ctx->npix))) return rc;
-    if (out_scalar && !out_model) {
+    if (out_scalar && !out_model && !ctx->wide) {
         if (mode == kModeLogL || mode == kModeChi2) {
             bool taken = false;
             if ((rc = run_host_stream(ctx, mode, P, batch, rowlen, out_scalar, &taken)) != MCALF_OK || taken) return rc;

@@ -137,6 +137,14 @@ struct mcalf_ctx {
     int stream_device = 0;                  // MCALF_STREAM_DEVICE=1 (diagnostic): the *_device scalar entries take the streaming launch too
     int stream_poll = 1;                    // MCALF_STREAM_POLL=0: wait for the stream's signal instead of polling h_ctl[1]
     double stream_timeout_s = 0.5;          // MCALF_STREAM_TIMEOUT: longest wait of a wave inside the kernel
+    // LSF wider than a workgroup tile (numpy boundary): the fused kernel runs WITHOUT convolution and continuum into
+    // d_wide, two more kernels do taps, periodic convolution, continuum and terms from HBM (host_abi.cpp: launch_wide).
+    // n_cap is 0 for such a context (the tile carries no halo); wide_n_cap is the half-width provisioned from specres_max.
+    int wide = 0, wide_n_cap = 0;
+    bool wide_stage1 = false;               // (transient: make_kargs builds the arguments of the convolution-free fused launch)
+    double *d_wide = nullptr, *d_wtaps = nullptr, *d_wpartial = nullptr, *d_wrows = nullptr;
+    SampleHdr* d_whdr = nullptr;
+    size_t cap_wide = 0, cap_wtaps = 0, cap_wpartial = 0, cap_wrows = 0, cap_whdr = 0;
     mcalf_launch_info_t last = {};      // what the last call did (mcalf_last_launch)
 };
 constexpr int kCtlWords = 64, kCtlArrived = 16;

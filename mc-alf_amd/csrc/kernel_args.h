@@ -203,5 +203,10 @@ MCALF_INTERNAL const void* finalize_kernel_ptr();              // (const double*
 MCALF_INTERNAL const void* hjert_kernel_ptr();                 // (const double* x, const double* y, long n, double* out, const double* tabs, int node_form)
 MCALF_INTERNAL const void* scale_cube_kernel_ptr();            // (const double* lo, const double* hi, const double* cube, long total, int ndim, int slot, int int_ncomp, double* theta)
 MCALF_INTERNAL const void* xcd_probe_kernel_ptr();             // (unsigned int* mask): ORs 1 << XCC_ID of every workgroup into *mask
+// LSF wider than a workgroup tile (kernels.hip, "wide" kernels): taps per live point, convolution + terms from HBM
+constexpr int kWideBlockThreads = 256;
+MCALF_INTERNAL const void* wide_taps_kernel_ptr();             // (const KArgs a, double* taps, long tap_stride, SampleHdr* hdr), grid = rows
+MCALF_INTERNAL const void* wide_conv_kernel_ptr();             // (const KArgs a, const double* flux, const double* taps, long tap_stride, const SampleHdr* hdr, int nblocks), grid = (nblocks, rows)
+MCALF_INTERNAL const void* wide_rows_kernel_ptr();             // (const double* rows, double* out, long batch): (R, cont, N, z, b) rows with cont := 1
 
 }  // namespace mcalf

@@ -1349,6 +1349,134 @@ __global__ void mcalf_scale_cube_kernel(const double* lo, const double* hi, cons
     theta[i] = v;
 }
 
+// ---- LSF wider than a workgroup tile: two more kernels behind the fused one ---------------------------------------------
+// The fused kernel convolves inside a 4096-pixel LDS tile, halo included.  A context whose LSF half-width does not fit
+// one (a very finely sampled spectrum, a very coarse resolution: the reference simply builds a longer kernel,
+// hires_fitter.py:458-464) runs the SAME fused kernel without its convolution and continuum -- the host passes it
+// velstep = 1e300 (hires_fitter.py:445: no convolution while R <= velstep), a fixed continuum of 1 -- into a buffer of
+// unconvolved spectra [rows][npix], and these two kernels do the rest from HBM: the taps of every live point (any half-width
+// up to the one provisioned from specres_max), then the periodic convolution, the continuum and the likelihood terms.
+// Rare path, written for clarity: one weight and one flux load per FMA.
+constexpr int kWideBlock = kWideBlockThreads;
+__device__ __forceinline__ double wide_block_sum(double v, double* red, int tid) {      // fixed order (deterministic)
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWideBlock / 64; ++w) s += red[w];
+    __syncthreads();
+    return s;
+}
+
+// Decode (R, continuum) of live point s as setup_sample() does (hires_fitter.py:412-425; mode OneComp: the row is (R, cont, N, z, b)).
+__device__ __forceinline__ void wide_decode(const KArgs& a, long s, double& R, double& cont) {
+    const int rowlen = (a.mode == kModeOneComp) ? 5 : a.ndim;
+    const double* p = a.P + (size_t)s * rowlen;
+    if (a.mode == kModeOneComp) { R = p[0]; cont = p[1]; return; }
+    R = a.freespecres ? sample_param(a, p, 0) : a.specres_fixed;
+    cont = a.freecont ? sample_param(a, p, a.freespecres ? 1 : 0) : a.contval_fixed;
+}
+
+// One workgroup per live point: its normalised Gaussian taps w[0 .. 2n] (astropy's Gaussian1DKernel divided by its sum),
+// the sum `bot` astropy's loop divides by, and the header (continuum, bot, n, bad).  Sums in fixed order.
+__global__ __launch_bounds__(kWideBlock) void mcalf_wide_taps_kernel(const KArgs a, double* taps, long tap_stride, SampleHdr* hdr) {
+    __shared__ double red[kWideBlock / 64];
+    const long s = blockIdx.x;
+    const int tid = threadIdx.x;
+    double R, cont;
+    wide_decode(a, s, R, cont);
+    const double sigma = (R / kFwhmToSigma) / a.velstep;         // :454
+    long n = 0;
+    bool bad = false;
+    if (R > a.velstep) {                                         // :445
+        const double nd = ceil(kKernelReach * sigma);            // :458
+        if (!(nd <= (double)a.n_cap)) bad = true;                // (beyond the half-width provisioned from specres_max; NaN too)
+        else n = (long)nd;
+    }
+    double* w = taps + (size_t)s * tap_stride;
+    const double inv2s2 = 0.5 / (sigma * sigma), amp = 1.0 / (sqrt(2.0 * M_PI) * sigma);
+    double part = 0.0;
+    for (long k = tid; k <= 2 * n; k += kWideBlock) {
+        const double dk = (double)(k - n);
+        const double g = (n == 0) ? 1.0 : exp_neg((dk * dk) * inv2s2) * amp;
+        w[k] = g;
+        part += g;
+    }
+    const double gsum = wide_block_sum(part, red, tid);
+    part = 0.0;
+    for (long k = tid; k <= 2 * n; k += kWideBlock) {
+        const double v = w[k] / gsum;                            // normalize_kernel=True
+        w[k] = v;
+        part += v;
+    }
+    const double bot = wide_block_sum(part, red, tid);
+    if (tid == 0) {
+        SampleHdr h;
+        h.cont = cont; h.bot = bot; h.ncl = 0; h.n = (int)n; h.bad = bad ? 1 : 0; h.ngeneral = 0;
+        hdr[s] = h;
+    }
+}
+
+// Workgroup (blockIdx.x, blockIdx.y) = pixels [256 x, 256 x + 256) of live point y:  model = (sum_k w_k flux[(i + k - n) mod
+// npix]) / bot x continuum (astropy boundary='wrap', taps in window order; hires_fitter.py:463-464, :447), then the model
+// row and / or the likelihood terms (:292-303) summed over the block into partial[y][x][4], which mcalf_finalize_kernel adds up.
+__global__ __launch_bounds__(kWideBlock) void mcalf_wide_conv_kernel(const KArgs a, const double* flux, const double* taps, long tap_stride,
+                                                                         const SampleHdr* hdr, int nblocks) {
+    __shared__ double red[kWideBlock / 64];
+    const long s = blockIdx.y;
+    const int tid = threadIdx.x;
+    const long i = (long)blockIdx.x * kWideBlock + tid;
+    const SampleHdr h = hdr[s];
+    const long n = h.n, npix = a.npix;
+    const double* f = flux + (size_t)s * npix;
+    const double* w = taps + (size_t)s * tap_stride;
+    const bool live = i < npix;
+    double mval = NAN;
+    if (live && !h.bad) {
+        long idx = (i - n) % npix;
+        if (idx < 0) idx += npix;
+        double top = 0.0;
+        for (long k = 0; k <= 2 * n; ++k) {
+            top = fma(f[idx], w[k], top);
+            if (++idx == npix) idx = 0;
+        }
+        mval = top / h.bot;
+        mval *= h.cont;                                          // :447
+    }
+    if (a.model && live) a.model[(size_t)s * npix + i] = mval;
+    if (a.mode != kModeLogL && a.mode != kModeChi2) return;     // (workgroup-uniform)
+    double acc = 0.0, nnz = 0.0, c4 = 0.0, c5 = 0.0;
+    if (live) {
+        const double d = a.obj[i] - mval;
+        double term = a.ispec2[i] * (d * d);
+        if (a.mode == kModeLogL) term = (term - a.lgis[i]) + a.log2pi;      // :294
+        if (!isnan(term)) acc = term;                                     // np.nansum
+        if (a.mode == kModeChi2 && mval != 0.0) nnz = 1.0;                // :241
+        if (a.asymm) {                                                     // :298-302
+            const double resid = d / a.err[i];
+            if (resid > 4.0) c4 = 1.0;
+            if (resid > 5.0) c5 = 1.0;
+        }
+    }
+    acc = wide_block_sum(acc, red, tid);
+    nnz = wide_block_sum(nnz, red, tid);
+    if (a.asymm) { c4 = wide_block_sum(c4, red, tid); c5 = wide_block_sum(c5, red, tid); }
+    if (tid == 0) {
+        if (h.bad) { acc = INFINITY; nnz = 1.0; }               // not computed: logL = -inf, chi2 = +inf (as in the fused kernel)
+        double* pr = a.partial + ((size_t)s * nblocks + blockIdx.x) * 4;
+        pr[0] = acc; pr[1] = nnz; pr[2] = c4; pr[3] = c5;
+    }
+}
+
+// Single-component rows (R, cont, N, z, b) with the continuum set to 1: what the fused kernel of a wide-LSF context gets
+// (it must deliver the UNCONVOLVED, continuum-free spectrum; mode OneComp reads the continuum from the row itself).
+__global__ void mcalf_wide_rows_kernel(const double* rows, double* out, long batch) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * 5) return;
+    out[i] = (i % 5 == 1) ? 1.0 : rows[i];
+}
+
 // One bit per XCD that runs a workgroup of the launch (the host launches a few workgroups per CU on the context's
 // stream: mcalf_create, mcalf_set_cu_mask): the XCDs a streaming launch on that stream can count on.
 __global__ void mcalf_xcd_probe_kernel(unsigned int* mask) {
@@ -1385,5 +1513,8 @@ const void* finalize_kernel_ptr() { return reinterpret_cast<const void*>(&mcalf_
 const void* hjert_kernel_ptr() { return reinterpret_cast<const void*>(&mcalf_hjert_kernel); }
 const void* scale_cube_kernel_ptr() { return reinterpret_cast<const void*>(&mcalf_scale_cube_kernel); }
 const void* xcd_probe_kernel_ptr() { return reinterpret_cast<const void*>(&mcalf_xcd_probe_kernel); }
+const void* wide_taps_kernel_ptr() { return reinterpret_cast<const void*>(&mcalf_wide_taps_kernel); }
+const void* wide_conv_kernel_ptr() { return reinterpret_cast<const void*>(&mcalf_wide_conv_kernel); }
+const void* wide_rows_kernel_ptr() { return reinterpret_cast<const void*>(&mcalf_wide_rows_kernel); }
 
 }  // namespace mcalf

@@ -66,9 +66,9 @@ def test_random_problem_matches_oracle(seed):
         try:
             fit = mcalf_amd.als_fitter(None, conv_mode=mode, **kw)
         except RuntimeError as exc:
-            # documented refusals: LSF wider than a tile can hold, or (JAX path) wider than the spectrum,
-            # where the reference's own jnp.where cannot broadcast
-            assert "MCALF_ERR_RANGE" in str(exc) or (mode == "jax" and "MCALF_ERR_INVALID" in str(exc))
+            # documented refusals, JAX semantics only: the fixed kernel grid wider than a tile can hold, or wider than the
+            # spectrum, where the reference's own jnp.where cannot broadcast (the numpy boundary convolves any width)
+            assert mode == "jax" and ("MCALF_ERR_RANGE" in str(exc) or "MCALF_ERR_INVALID" in str(exc))
             continue
         with fit:
             got = fit.loglike_batch(P)

@@ -1,0 +1,102 @@
+"""GPU: an LSF wider than a workgroup tile.  The fused kernel convolves inside a 4096-pixel LDS tile, halo included; the
+reference simply builds a longer kernel (hires_fitter.py:458-464, astropy `convolve(..., boundary='wrap')`).  Round 5:
+such a context is no longer refused (MCALF_ERR_RANGE) -- the fused kernel runs without convolution and continuum, and two
+more kernels form every live point's taps and convolve periodically from HBM (host_abi.cpp: launch_wide) -- same entry
+points, same conventions.  Checked against the numpy oracle: kernels several times longer than the spectrum (the window
+wraps round it more than once), free resolution and continuum, fillers, logL / chi2 / model / single components / unit-cube
+input, host and device entries, a resolution beyond the provisioned maximum."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import mcalf_amd
+from mcalf_amd import _lib, workloads
+from cases import problem_from_kwargs
+from oracle import numpy_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+CIV = [(1548.204, 0.1899, 2.643e8), (1550.781, 0.09475, 2.628e8)]
+
+
+def _problem(npix, velstep, specres, contval=(1.0,), nfill=0, seed=0):
+    rng = np.random.default_rng(seed)
+    wl = np.linspace(6180.0, 6220.0, npix + 2)[1:-1]
+    flux = 1 + rng.normal(0, 0.03, npix)
+    err = rng.uniform(0.01, 0.05, npix)
+    return dict(fitrange=[[6180.0, 6220.0]], fitlines=["CIV 1548", "CIV 1550"], linepars=CIV, ncomp=[1, 3], nfill=nfill,
+                specres=list(specres), contval=list(contval), Nrange=[12.0, 14.5], brange=[5.0, 40.0], zrange=[2.995, 3.012],
+                spectrum=(wl, flux, err), velstep=float(velstep))
+
+
+@pytest.mark.parametrize("npix,velstep,specres,contval,nfill", [
+    (1500, 0.004, (8.0,), (1.0,), 0),            # n = 2578: wider than a tile, 1.7 x the spectrum on each side
+    (333, 0.0031, (6.0, 9.0), (0.9, 1.1), 2),    # free resolution and continuum, fillers; the window wraps ~ 22 times
+    (4500, 0.0045, (8.0, 8.5), (1.0,), 0),       # two pixel tiles in the fused stage, n up to 2438
+])
+def test_wide_lsf_context_matches_the_oracle(npix, velstep, specres, contval, nfill):
+    kw = _problem(npix, velstep, specres, contval, nfill, seed=npix)
+    prob = problem_from_kwargs(kw)
+    rng = np.random.default_rng(7 + npix)
+    P = workloads.draw_P(kw, 6, rng)
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        n_cap = fit.info.n_cap
+        assert 2 * n_cap + 64 > 4096                            # the case the fused kernel's tile cannot hold
+        assert n_cap == int(np.ceil(3.0348 * (max(specres) / 2.354820) / velstep))
+        got = fit.loglike_batch(P)
+        want = o.loglike_batch(prob, P)
+        assert np.all(np.abs(got - want) < 1e-7 + 2e-9 * np.abs(want)), (got, want)
+        for targ in (False, True):
+            m = fit.model_batch(P[:2], targonly=targ)
+            for a, p in zip(m, P[:2]):
+                assert np.abs(a - o.reconstruct_spec(prob, p, targonly=targ)).max() < 2e-10
+        chi2 = fit.chi2_batch(P)
+        want_chi2 = np.array([o.chi2(prob, p) for p in P])
+        assert np.allclose(chi2, want_chi2, rtol=1e-11, atol=1e-9)
+        # the reference's one-theta callables and the single-component spectra
+        assert fit.lnlhood_pc(P[3])[0] == got[3] and fit.lnlhood_dy(P[4]) == got[4]
+        s = fit.startind
+        one = fit.reconstruct_onecomp(max(specres), 0.95, P[0][s + 1], P[0][s + 2], P[0][s + 3])
+        assert np.abs(one - o.reconstruct_onecomp(prob, max(specres), 0.95, P[0][s + 1], P[0][s + 2], P[0][s + 3])).max() < 2e-10
+        # device entry == host entry, bit for bit; unit-cube input == the two-step path
+        dP = torch.from_numpy(P).cuda()
+        out = torch.full((len(P),), float("nan"), dtype=torch.float64, device="cuda")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(fit._lib.mcalf_loglike_batch_device(fit._ctx, dP.data_ptr(), len(P), out.data_ptr(), st), fit._ctx)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), got)
+        cubes = rng.random((5, P.shape[1]))
+        theta, ll = fit.loglike_cube_batch(cubes)
+        assert np.array_equal(theta, fit.scale_cube_batch(cubes)) and np.array_equal(ll, fit.loglike_batch(theta))
+        # a larger batch than the one-launch variant takes (set-up kernel + fused kernel in the first stage): same bits
+        big = workloads.draw_P(kw, 700, rng)
+        big[:6] = P
+        assert np.array_equal(fit.loglike_batch(big)[:6], got)
+
+
+def test_wide_lsf_resolution_beyond_the_provisioned_maximum_and_no_convolution():
+    """Free resolution in [6, 9] km/s on a 0.0031 km/s grid: a row with R = 12 is beyond the provisioned half-width --
+    NaN model, logL = -inf, chi2 = +inf, as in every other context -- and a row with R below the velocity step is not
+    convolved at all (hires_fitter.py:445)."""
+    kw = _problem(333, 0.0031, (6.0, 9.0), (1.0,), 0, seed=5)
+    prob = problem_from_kwargs(kw)
+    P = workloads.draw_P(kw, 4, np.random.default_rng(11))
+    P[1, 0] = 12.0
+    P[2, 0] = 0.003
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        got = fit.loglike_batch(P)
+        chi2 = fit.chi2_batch(P)
+        m = fit.model_batch(P)
+        assert got[1] == -np.inf and chi2[1] == np.inf and np.isnan(m[1]).all()
+        keep = [0, 2, 3]
+        want = o.loglike_batch(prob, P[keep])
+        assert np.all(np.abs(got[keep] - want) < 1e-7 + 2e-9 * np.abs(want))
+        assert np.abs(m[2] - o.reconstruct_spec(prob, P[2])).max() < 2e-10
+
+
+def test_jax_semantics_keep_their_fixed_grid_inside_the_tile():
+    kw = _problem(1500, 0.004, (8.0,), (1.0,), 0, seed=1)
+    with pytest.raises(RuntimeError, match="MCALF_ERR_RANGE|MCALF_ERR_INVALID"):
+        mcalf_amd.als_fitter(None, conv_mode="jax", **kw)
