@@ -15,7 +15,8 @@ void resident_stop(mcalf_ctx* ctx) {
 }
 
 bool resident_serves(const mcalf_ctx* ctx, int mode, int64_t batch, int rowlen, bool from_cube) {
-    return ctx->resident_us > 0 && mode == kModeLogL && batch == 1 && ctx->ntiles == 1 && rowlen <= kResRowMax && !from_cube &&
+    // (a wide-LSF context convolves in a second kernel: its calls launch)
+    return ctx->resident_us > 0 && mode == kModeLogL && batch == 1 && ctx->ntiles == 1 && !ctx->wide && rowlen <= kResRowMax && !from_cube &&
            !ctx->profiling;
 }
 
@@ -230,9 +231,10 @@ extern "C" int mcalf_broker_serve_resident(mcalf_ctx* ctx, void* boxes, int32_t 
     if (!boxes || !stop || slots < 1 || slots > ctx->num_cu || idle_us < 1 || idle_us > 1000000 || (reinterpret_cast<uintptr_t>(boxes) & 63))
         return set_err(ctx, MCALF_ERR_INVALID, "resident broker: 1 .. %d mailboxes (one co-resident workgroup per compute unit of this "
                        "device) at a 64-byte aligned address, idle limit 1 .. 1000000 us", ctx->num_cu);
-    if (ctx->ntiles != 1 || ctx->ndim > kResRowMax)
-        return set_err(ctx, MCALF_ERR_RANGE, "resident broker: the spectrum must fit one pixel tile and a row 64 parameters "
-                       "(%d tiles, %d parameters): use mcalf_broker_serve", ctx->ntiles, ctx->ndim);
+    if (ctx->ntiles != 1 || ctx->wide || ctx->ndim > kResRowMax)
+        return set_err(ctx, MCALF_ERR_RANGE, "resident broker: the spectrum must fit one pixel tile WITH its LSF halo and a row 64 "
+                       "parameters (%d tiles, %d parameters%s): use mcalf_broker_serve", ctx->ntiles, ctx->ndim,
+                       ctx->wide ? ", LSF wider than a tile" : "");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ResidentBox* hb = static_cast<ResidentBox*>(boxes);
     const size_t bytes = (size_t)slots * sizeof(ResidentBox);

@@ -100,3 +100,21 @@ def test_jax_semantics_keep_their_fixed_grid_inside_the_tile():
     kw = _problem(1500, 0.004, (8.0,), (1.0,), 0, seed=1)
     with pytest.raises(RuntimeError, match="MCALF_ERR_RANGE|MCALF_ERR_INVALID"):
         mcalf_amd.als_fitter(None, conv_mode="jax", **kw)
+
+
+def test_wide_context_is_not_served_by_resident_evaluators():
+    """The resident one-theta evaluator runs the one-launch variant's item, which convolves inside the tile: a wide-LSF
+    context keeps launching (same values as without the switch), and the resident broker refuses it with a message."""
+    kw = _problem(333, 0.0031, (8.0,), (1.0,), 0, seed=3)
+    P = workloads.draw_P(kw, 3, np.random.default_rng(1))
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        want = fit.loglike_batch(P)
+        fit.set_resident(300)
+        got = np.array([fit.lnlhood_dy(p) for p in P])
+        assert np.array_equal(got, want) and fit.last_launch().inline_setup != 3
+        fit.set_resident(0)
+        boxes = (C.c_char * (2 * 576 + 64))()
+        base = (C.addressof(boxes) + 63) & ~63
+        stop = C.c_uint64(0)
+        rc = fit._lib.mcalf_broker_serve_resident(fit._ctx, base, 1, C.addressof(stop), 100, None, 0.01)
+        assert rc == _lib.MCALF_ERR_RANGE and b"wider than a tile" in fit._lib.mcalf_last_error(fit._ctx)
