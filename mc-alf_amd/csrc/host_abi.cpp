@@ -420,6 +420,15 @@ extern "C" int mcalf_set_cu_mask(mcalf_ctx* ctx, const uint32_t* mask, int32_t n
     return stream_probe_xcds(ctx);
 }
 
+// Live points per pass of a wide-LSF launch (launch_wide): each of its scratch buffers -- unconvolved spectra, taps -- stays
+// below 512 MB; 0 when a single live point does not fit.
+static int64_t wide_rows_per_pass(const mcalf_ctx* ctx, int64_t batch) {
+    constexpr size_t kScratchBytes = (size_t)512 << 20;
+    const size_t per_row = sizeof(double) * (size_t)std::max<int64_t>(ctx->npix, 2 * (int64_t)ctx->wide_n_cap + 1);
+    if (per_row > kScratchBytes) return 0;
+    return std::min<int64_t>(batch, std::min<int64_t>(65535, std::max<int64_t>(1, (int64_t)(kScratchBytes / per_row))));
+}
+
 static int grow_sample_ws(mcalf_ctx* ctx, int64_t batch) {
     int rc;
     if ((rc = grow(ctx, &ctx->d_recs, &ctx->cap_recs, (size_t)batch * ctx->ncl_cap * kRecStride))) return rc;
@@ -437,6 +446,16 @@ extern "C" int mcalf_reserve(mcalf_ctx* ctx, int64_t batch) {
     if ((rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
     if ((rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4))) return rc;
     if ((rc = grow_sample_ws(ctx, batch))) return rc;
+    if (ctx->wide && batch > 0) {                         // the scratch of a wide-LSF launch (one pass of launch_wide)
+        const int64_t rows = wide_rows_per_pass(ctx, batch);
+        if (rows < 1) return set_err(ctx, MCALF_ERR_RANGE, "wide LSF: one live point exceeds the scratch of a pass");
+        const int nblocks = (int)((ctx->npix + kWideBlockThreads - 1) / kWideBlockThreads);
+        if ((rc = grow(ctx, &ctx->d_wide, &ctx->cap_wide, (size_t)rows * ctx->npix))) return rc;
+        if ((rc = grow(ctx, &ctx->d_wtaps, &ctx->cap_wtaps, (size_t)rows * (2 * (size_t)ctx->wide_n_cap + 1)))) return rc;
+        if ((rc = grow(ctx, &ctx->d_whdr, &ctx->cap_whdr, (size_t)rows))) return rc;
+        if ((rc = grow(ctx, &ctx->d_wpartial, &ctx->cap_wpartial, (size_t)rows * nblocks * 4))) return rc;
+        if ((rc = grow(ctx, &ctx->d_wrows, &ctx->cap_wrows, (size_t)rows * 5))) return rc;
+    }
     return MCALF_OK;
 }
 
@@ -605,10 +624,8 @@ static int launch_wide(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch
     const int64_t npix = ctx->npix, tapw = 2 * (int64_t)ctx->wide_n_cap + 1;
     const int rowlen = (mode == kModeOneComp) ? 5 : ctx->ndim;
     const bool reduces = (mode == kModeLogL || mode == kModeChi2);
-    constexpr size_t kScratchBytes = (size_t)512 << 20;           // per buffer and pass
-    const size_t per_row = sizeof(double) * (size_t)std::max(npix, tapw);
-    if (per_row > kScratchBytes) return set_err(ctx, MCALF_ERR_RANGE, "wide LSF: one live point needs %zu bytes of scratch", per_row);
-    const int64_t rows = std::min<int64_t>(batch, std::min<int64_t>(65535, std::max<int64_t>(1, (int64_t)(kScratchBytes / per_row))));
+    const int64_t rows = wide_rows_per_pass(ctx, batch);
+    if (rows < 1) return set_err(ctx, MCALF_ERR_RANGE, "wide LSF: one live point exceeds the scratch of a pass");
     const int nblocks = (int)((npix + kWideBlockThreads - 1) / kWideBlockThreads);
     int rc;
     if ((rc = launch_preflight(ctx, kModeModel, rows))) return rc;
