@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>   // types only: the library is resolved at run time (mcalf_comm_*), never linked
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>

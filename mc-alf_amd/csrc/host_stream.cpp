@@ -2,7 +2,6 @@
 // mcalf_fused_kernel<..., kStream = true>).
 #include "host_ctx.h"
 
-
 namespace {
 // MCALF_STREAM_TRACE=1 (diagnostic): mean host-side microseconds per phase of the streaming entry, printed when the
 // context is destroyed
@@ -20,21 +19,6 @@ void stream_trace_report(const mcalf_ctx* ctx) {
     g_stream_trace = StreamTrace();
 }
 
-// Large scalar-output batches through host pointers, the default plan: ONE streaming launch, no copy commands.
-//
-//   host                                         device (mcalf_fused_kernel<..., kStream = true>, the persistent grid)
-//   launch the kernel                            every workgroup: set up eight of the first `eager_rows` live points
-//   pageable P: copy the rows into the           (the rows the grid's first items need), reading the parameter rows
-//     page-locked block, 128 at a time,          over PCIe from the page-locked block; then walk over work items.  The first
-//     publishing the count after each            `stream_wgs` workgroups go on setting up the remaining rows, in ticket order,
-//   (page-locked P: nothing to do)               as the host's count allows, and join the others at the item queue afterwards.
-//   poll the word the last workgroup out         An item enters the component loop once its row's stamp is there; logL goes
-//     writes; copy logL out if pageable          straight into page-locked memory; the last workgroup out re-arms the queues.
-//
-// Against the row-block pipeline (run_host_pipelined) this removes the copy commands, three of four set-up launches and
-// the tails of the sub-threshold launches, and the GPU starts before a single row has been staged.  `*taken` = false when
-// the call does not qualify (the caller then runs the pipeline); a wait that runs out inside the kernel (host thread
-// stalled for longer than MCALF_STREAM_TIMEOUT) fails over to the pipeline too, after the grid has drained.
 // Workspaces of the streaming launch for `batch` live points, and the words it shares with the host.
 int stream_prepare(mcalf_ctx* ctx, int mode, int64_t batch) {
     int rc;
@@ -197,6 +181,23 @@ void host_scale_cube(const mcalf_ctx* ctx, const double* cube, int64_t batch, do
     }
 }
 
+// Large scalar-output batches through host pointers, the default plan: ONE streaming launch, no copy commands.
+//
+//   host                                         device (mcalf_fused_kernel<..., kStream = true>, the persistent grid)
+//   launch the kernel                            every workgroup: set up eight of the first `eager_rows` live points
+//   pageable P: copy the rows into the           (the rows the grid's first items need), reading the parameter rows
+//     page-locked block, 128 at a time,          over PCIe from the page-locked block; then walk over work items.  The first
+//     publishing the count after each            `stream_wgs` workgroups go on setting up the remaining rows, in ticket order,
+//   (page-locked P: nothing to do)               as the host's count allows, and join the others at the item queue afterwards.
+//   poll the word the last workgroup out         An item enters the component loop once its row's stamp is there; logL goes
+//     writes; copy logL out if pageable          straight into page-locked memory; the last workgroup out re-arms the queues.
+//
+// Against the row-block pipeline (run_host_pipelined) this removes the copy commands, three of four set-up launches and
+// the tails of the sub-threshold launches, and the GPU starts before a single row has been staged.  `*taken` = false when
+// the call does not qualify (the caller then runs the pipeline); a wait that runs out inside the kernel (host thread
+// stalled for longer than MCALF_STREAM_TIMEOUT) fails over to the pipeline too, after the grid has drained.
+// On any device shape but the eight XCDs of an unpartitioned MI355X the call does not qualify either (stream_probe_xcds), and
+// a launch whose kernel reports an XCD without workgroups is discarded like one that timed out.
 int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, double* out_scalar, bool* taken,
                     bool from_cube, double* theta_out) {
     *taken = false;
