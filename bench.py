@@ -700,6 +700,8 @@ def main():
                 out["roofline_valu"].update({"achieved": ex, "frac": ex / FP64_VALU_PEAK_TFLOPS})
             if "issue" in pmc:
                 out["roofline_issue"] = issue_model(pmc["issue"], kern_ms)
+        # (the same two figures under explicit names, whichever convention a reader expects for `value`)
+        out["value_device_resident"], out["ms_per_step_device_resident"] = out["value"], ms_per_step
         if host_api:
             out["value_host_api"] = host_api["value"]
             out["ms_per_step_host_api"] = host_api["ms_per_step"]
