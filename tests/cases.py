@@ -28,3 +28,13 @@ def seeded_noise():
     """The noise realisation of testdata/generate_from_model.py:52-54."""
     np.random.seed(42)
     return np.random.normal(0, 0.02, size=1998)
+
+
+def require_streaming_shape(fit):
+    """Skip a test that asserts the STREAMING launch of the host-pointer entries when the context's stream does not reach
+    exactly the eight XCDs of an unpartitioned MI355X (a DPX / QPX / CPX partition): there the library takes the row-block
+    pipeline by design (tests/test_gpu_stream_shape.py covers that decision), and only the path assertions would fail."""
+    import pytest
+    mask = fit.last_launch().xcd_mask
+    if mask != 0xFF:
+        pytest.skip(f"this device's stream reaches XCDs {mask:#x}, not 0xff: the streaming launch is not taken here")

@@ -8,7 +8,7 @@ import torch
 
 import mcalf_amd
 from mcalf_amd import _lib, workloads
-from cases import oracle_synth
+from cases import oracle_synth, require_streaming_shape
 
 pytestmark = pytest.mark.gpu
 
@@ -131,6 +131,8 @@ def test_cube_host_entry_takes_the_fast_paths_of_the_theta_entry(cfg, n, path):
     host under the launch: theta bit-equal to the numpy transform, logL bit-equal to the two-step path, both int() flavours."""
     kw, _, seed = workloads.config(cfg, oracle_synth)
     with mcalf_amd.als_fitter(None, **kw) as fit:
+        if path == "stream":
+            require_streaming_shape(fit)
         cubes = np.random.default_rng(seed + 300).random((n, fit.ndim))
         for int_ncomp in (True, False):
             theta, logL = fit.loglike_cube_batch(cubes, int_ncomp=int_ncomp)

@@ -21,7 +21,7 @@ import torch
 
 import mcalf_amd
 from mcalf_amd import _lib, workloads
-from cases import oracle_synth
+from cases import oracle_synth, require_streaming_shape
 
 pytestmark = pytest.mark.gpu
 
@@ -62,6 +62,7 @@ def test_a_larger_batch_after_exactly_one_streamed_call_is_not_answered_by_the_o
     assert np.isfinite(want).all()
     for sizes in ((n, 2 * n), (n, 2 * n, 3 * n, n), (2 * n, n, 3 * n)):
         with mcalf_amd.als_fitter(None, **kw) as fit:           # a FRESH context per sequence: its first streamed call is call 1
+            require_streaming_shape(fit)
             for m in sizes:
                 out = np.full(m, np.nan)
                 fit.loglike_batch(P[:m], out=out)
@@ -81,6 +82,7 @@ def test_cu_masked_context_gives_the_same_bits_and_never_streams_onto_xcds_it_ca
     n = 2600
     P = workloads.draw_P(kw, n, np.random.default_rng(seed + 99))
     with mcalf_amd.als_fitter(None, **kw) as fit:
+        require_streaming_shape(fit)
         want = _device_logl(fit, P)
         assert np.array_equal(fit.loglike_batch(P), want)
         ll = fit.last_launch()

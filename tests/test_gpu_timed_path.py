@@ -11,7 +11,7 @@ import torch
 
 import mcalf_amd
 from mcalf_amd import _lib, workloads
-from cases import oracle_synth, problem_from_kwargs
+from cases import oracle_synth, problem_from_kwargs, require_streaming_shape
 from oracle import c_oracle
 from oracle import numpy_oracle as o
 
@@ -147,6 +147,7 @@ def test_pipelined_host_entry_is_the_path_taken_and_is_bit_equal(monkeypatch):
     Ppin = torch.from_numpy(P).pin_memory().numpy()
     dP = torch.from_numpy(P).cuda()
     with mcalf_amd.als_fitter(None, **kw) as fit:
+        require_streaming_shape(fit)
         whole = _device_logl(fit, dP, n)
         assert np.isfinite(whole).all()
         for k, blocks_pageable, blocks_pinned in ((0, 1, 1), (1, 1, 1), (2, 2, 2), (5, 5, 5)):
@@ -222,6 +223,7 @@ def test_streaming_host_entry_one_launch_no_copy_commands(cfg, conv, n, monkeypa
     if cfg == "E":
         # a tiled spectrum takes the row-block pipeline by default (measured faster); MCALF_STREAM=2 streams it as well
         with mcalf_amd.als_fitter(None, **kw) as fit:
+            require_streaming_shape(fit)
             fit.loglike_batch(P)
             assert fit.last_launch().path == _lib.MCALF_PATH_HOST_PIPELINED
         monkeypatch.setenv("MCALF_STREAM", "2")
@@ -233,6 +235,7 @@ def test_streaming_host_entry_one_launch_no_copy_commands(cfg, conv, n, monkeypa
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with mcalf_amd.als_fitter(None, **kw) as fit:
+            require_streaming_shape(fit)
             if not ref:
                 ref["logl"] = _device_logl(fit, dP, n)
                 assert fit.last_launch().path == _lib.MCALF_PATH_DEVICE
