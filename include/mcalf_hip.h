@@ -311,7 +311,7 @@ enum {
 int mcalf_last_launch(const mcalf_ctx* ctx, mcalf_launch_info_t* info);
 
 /* Restrict the context's own streams (the host-pointer entries; *_device entries run on the CALLER's stream) to the
- * compute units of `mask` -- bit i of word i / 32 = CU i in the runtime's numbering (hipExtStreamCreateWithCUMask; on a
+ * compute units of `mask` -- bit i % 32 of word i / 32 = CU i in the runtime's numbering (hipExtStreamCreateWithCUMask; on a
  * multi-XCD device consecutive bits go round the XCDs: bit i = CU i / 8 of XCD i % 8) -- as an embedding application does to
  * share one GPU between ranks.  nwords = 0 removes the mask.  The context waits for its streams, re-creates them and probes
  * again which XCDs they reach: on anything but all eight XCDs of an unpartitioned MI355X large host-pointer batches take the
