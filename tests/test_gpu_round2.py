@@ -197,3 +197,34 @@ def test_two_rank_job_through_the_product_path_on_one_gpu():
     assert sp["kernels_ms"] > 0 and sp["exchange_ms"] >= 0 and sp["join_ms"] >= 0
     assert sp["step_ms_synchronous"] == pytest.approx(sp["kernels_ms"] + sp["exchange_ms"] + sp["join_ms"])
     assert all(isinstance(out["gathers"][k], str) and out["gathers"][k].startswith("skipped") for k in ("inlib", "inlib_overlap"))
+
+
+def test_from_the_reference_s_own_ini_and_ascii_inputs_to_the_golden_logl(tmp_path, monkeypatch):
+    """What a user of the reference does (cli.py:55-76): `mcalf fit.cfg` -> `readconfig` -> `als_fitter(specfile, wavefit,
+    linelist, ncomp, ...)` read from disk.  Here with the reference's OWN example configuration and data file
+    (tests/golden/fit.cfg, civ_mock_spec_multicomp.txt: byte copies) laid out as the configuration expects them
+    (`./testdata/...`), through `als_fitter.from_config`: 1998 pixels in 6180-6220 A, ncomp 8-11 -> ndim 34, velstep the
+    clipped median of the file's own grid; logL and chi2 at the 10-component truth equal the golden values (the 11th
+    component slot is inactive: int(p[0]) = 10), and the reference's solver-facing callables agree with each other."""
+    import json
+    import shutil
+    from mcalf_amd.routines import hires_fitter as h
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    os.makedirs(tmp_path / "testdata")
+    shutil.copy(os.path.join(gold, "civ_mock_spec_multicomp.txt"), tmp_path / "testdata" / "civ_mock_spec_multicomp.txt")
+    shutil.copy(os.path.join(gold, "fit.cfg"), tmp_path / "fit.cfg")
+    monkeypatch.chdir(tmp_path)
+    pars = h.readconfig("fit.cfg")
+    g = json.load(open(os.path.join(gold, "derived_goldens.json")))
+    with h.als_fitter.from_config(pars) as fit:
+        assert (fit.ndim, fit.startind, fit.endind, fit.ncompmin, fit.ncompmax, fit.nfill) == (34, 0, 34, 8, 11, 0)
+        assert fit.obj_wl.size == 1998 and abs(fit.velstep - g["velstep"]) < 1e-12
+        assert not fit.freespecres and not fit.freecont and fit.fitlines == ["CIV 1548", "CIV 1550"]
+        p = np.concatenate([workloads.truth_vector(10), [13.0, 3.0, 20.0]])      # the 11th slot: never evaluated
+        pc = fit.lnlhood_pc(p)
+        assert pc[1] == [] and abs(pc[0] - g["G3_logL_truth"]) < 1e-7
+        assert fit.lnlhood_dy(p) == pc[0] and fit.lnlhood_mn(list(p), 34, 34) == pc[0]
+        assert abs(fit.chi2(p) - g["G3_chi2_truth"]) < 1e-7
+        # the prior transform of the solver branch (cli.py:110: _scale_cube_pc) stays inside the configuration's box
+        th = fit._scale_cube_pc(np.full(34, 0.5))
+        assert th[0] == 9.0 and abs(th[1] - 13.25) < 1e-12 and abs(th[2] - 3.0) < 1e-12 and abs(th[3] - 25.0) < 1e-12

@@ -107,3 +107,28 @@ def test_total_column_reference_and_intended(monkeypatch):
     # expressions are the reference's): the same number out of both
     q = np.array([3.0, 13.0, 3.0, 10.0, 13.5, 3.001, 12.0, 14.0, 3.002, 15.0, 12.0, 23.8, 5.0, 12.5, 23.81, 6.0, 1.0])
     assert f.calc_N(q) == o.calc_N_reference(prob, q)
+
+
+def test_readconfig_on_the_reference_s_own_example_configuration():
+    """tests/golden/fit.cfg is the reference's testdata/fit.cfg, byte for byte: the INI file `mcalf` is started with
+    (cli.py:60-76).  Expected values by reading the reference's parser (hires_fitter.py:762-969): strings split on commas
+    and stripped, numeric lists as float / int arrays, `nmaxcols` = the first character only, settings sections with
+    'True' / 'False' turned into booleans and everything else left a string, `device` stripped by configparser."""
+    r = h.readconfig(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fit.cfg"))
+    assert r["specfile"] == "./testdata/civ_mock_spec_multicomp.txt"          # datadir + specfile (:909)
+    assert r["wavefit"] == [(6180.0, 6220.0)] and r["linelist"] == ["CIV 1548", "CIV 1550"]
+    assert r["coldef"] == ["Wave", "Flux", "Err"] and r["solver"] == "jaxns" and r["asymmlike"] is False
+    assert np.array_equal(r["specres"], [8.0]) and np.array_equal(r["ncomp"], [8, 11]) and r["ncomp"].dtype.kind == "i"
+    assert r["nfill"] == 0 and np.array_equal(r["contval"], [1.0])
+    assert np.array_equal(r["Nrange"], [12.0, 14.5]) and np.array_equal(r["brange"], [10.0, 40.0])
+    assert np.array_equal(r["zrange"], [2.99, 3.01])
+    assert np.array_equal(r["Nrangefill"], [11.5, 16.0]) and np.array_equal(r["brangefill"], [1.0, 30.0]) and r["wrangefill"] is None
+    assert r["chaindir"] == "testdata/output/fits/" and r["plotdir"] == "testdata/output/plots/" and r["chainfmt"] == "pc_fits_{0}"
+    assert r["nmaxcols"] == 3 and np.array_equal(r["yrange"], [-0.1, 1.2])
+    assert r["dofit"] is True and r["doplot"] is True and r["showprogress"] is False and r["device"] == "cpu"
+    assert r["jaxns_settings"] == {"max_samples": "2000", "num_live_points": "200", "difficult_model": True}
+    assert r["pc_settings"]["nlive"] == "150" and r["pc_settings"]["do_clustering"] is False and r["pc_settings"]["equals"] is True
+    assert len(r["pc_settings"]) == 13 and "mn_settings" not in r
+    assert set(r) == {"specfile", "wavefit", "linelist", "coldef", "asymmlike", "solver", "specres", "chaindir", "plotdir", "chainfmt",
+                      "ncomp", "nfill", "Nrange", "brange", "zrange", "Nrangefill", "brangefill", "wrangefill", "contval", "nmaxcols",
+                      "yrange", "dofit", "doplot", "showprogress", "pc_settings", "jaxns_settings", "device"}
