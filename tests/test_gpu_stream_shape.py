@@ -105,8 +105,11 @@ def test_cu_masked_context_gives_the_same_bits_and_never_streams_onto_xcds_it_ca
             else:
                 assert (ll.path, ll.stream_fallback) == (STREAM, 0) and ll.stream_wgs_min >= 1
             assert np.array_equal(fit.chi2_batch(P), fit.chi2_batch(P[::-1].copy())[::-1])
-            # small calls and model output are not affected
+            # small calls and model output are not affected; the row-block pipeline runs on streams created under the mask
             assert np.array_equal(fit.loglike_batch(P[:5]), want[:5])
+            fit.set_chunks(3)
+            assert np.array_equal(fit.loglike_batch(P), want) and fit.last_launch().path == PIPELINED
+            fit.set_chunks(0)
         fit.set_cu_mask(None)
         assert np.array_equal(fit.loglike_batch(P), want)
         ll = fit.last_launch()
