@@ -192,6 +192,82 @@ def issue_model(iss, kern_ms):
                     "pipe limit explains: dependency and LDS-latency stalls that four waves per SIMD do not cover"}
 
 
+PATH_NAME = {_lib.MCALF_PATH_HOST_STREAM: "one streaming launch (MCALF_PATH_HOST_STREAM)",
+             _lib.MCALF_PATH_HOST_ZEROCOPY: "zero-copy small call, completion read off the results (MCALF_PATH_HOST_ZEROCOPY)",
+             _lib.MCALF_PATH_HOST_PIPELINED: "row-block pipeline (MCALF_PATH_HOST_PIPELINED)",
+             _lib.MCALF_PATH_HOST_STAGED: "staged copies (MCALF_PATH_HOST_STAGED)"}
+
+
+def median_pass_ms(fn, k, sync):
+    """Milliseconds per step of `fn`: passes of exactly k steps bracketed by `sync()`, repeated until a pass is long enough
+    to time (MIN_PASS_MS) -- the median pass."""
+    def one():
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        sync()
+        return time.perf_counter() - t0
+    first = one()
+    npass = 1 if first * 1e3 >= MIN_PASS_MS else min(15, 2 * int(math.ceil(MIN_PASS_MS / max(first * 1e3, 1e-3))) + 1)
+    times = sorted([first] + [one() for _ in range(npass - 1)])
+    return times[len(times) // 2] / k * 1e3
+
+
+def config_leg(config, rows=None, steps=20, device=0, parity_rows=64):
+    """One further BASELINE configuration on this GPU, both ways: the device-resident step (P in HBM, logL left in HBM: the
+    bench contract's `value`) and SURVEY.md 8(d)'s step through the host-pointer entry (P from host memory and logL back
+    inside every step; pageable numpy arrays, then page-locked ones), the path the library took, and a parity spot check
+    of `parity_rows` rows spread over the batch against the numpy / scipy oracle (the checker; not timed)."""
+    kw, batch, seed = workloads.config(config, hip_synth)
+    rows = rows or batch
+    P = np.ascontiguousarray(workloads.draw_P(kw, batch, np.random.default_rng(seed), damped=2 if config == "E" else 0)[:rows])
+    dev = torch.device("cuda", device)
+    with mcalf_amd.als_fitter(None, device=device, **kw) as fit:
+        _lib.check(fit._lib.mcalf_reserve(fit._ctx, rows), fit._ctx)
+        dP = torch.from_numpy(P).to(dev)
+        out = torch.empty(rows, dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream()
+        st = C.c_void_p(stream.cuda_stream)
+        launch, ctx, pP, pO = fit._lib.mcalf_loglike_batch_device, fit._ctx, dP.data_ptr(), out.data_ptr()
+
+        def dev_step():
+            rc = launch(ctx, pP, rows, pO, st)
+            if rc:
+                _lib.check(rc, ctx)
+        sync = torch.cuda.synchronize
+        for _ in range(3):
+            dev_step()
+        ms_dev = median_pass_ms(dev_step, steps, sync)
+        logl_dev = out.cpu().numpy().copy()
+        ll_dev = fit.last_launch()
+        out_h = np.empty(rows)
+        fit.loglike_batch(P, out=out_h)
+        fit.loglike_batch(P, out=out_h)
+        ms_host = median_pass_ms(lambda: fit.loglike_batch(P, out=out_h), steps, sync)
+        llh = fit.last_launch()
+        P_pin = torch.from_numpy(P).pin_memory().numpy()
+        out_pin = torch.full((rows,), float("nan"), dtype=torch.float64).pin_memory().numpy()
+        fit.loglike_batch(P_pin, out=out_pin)
+        ms_pin = median_pass_ms(lambda: fit.loglike_batch(P_pin, out=out_pin), steps, sync)
+        nc = P[:, fit.startind].astype(int)
+        comp_pix = float(nc.sum()) * fit.obj_wl.size
+        idx = np.unique(np.linspace(0, rows - 1, min(parity_rows, rows)).astype(int))
+        from oracle import numpy_oracle as oracle
+        prob = oracle_problem(kw)
+        want = np.array([oracle.lnlhood_worker(prob, P[i]) for i in idx])
+        return {"workload": WORKLOAD_LABEL[config], "rows": rows, "npix": int(fit.obj_wl.size), "ndim": fit.ndim,
+                "tiles_per_sample": fit.info.ntiles, "steps": steps,
+                "ms_per_step_device_resident": ms_dev, "value_device_resident": comp_pix / (ms_dev * 1e-3),
+                "ms_per_step_host_api": ms_host, "value_host_api": comp_pix / (ms_host * 1e-3),
+                "ms_per_step_host_api_pinned": ms_pin,
+                "host_over_device": ms_host / ms_dev, "host_over_device_pinned": ms_pin / ms_dev,
+                "path_host_api": PATH_NAME.get(llh.path, str(llh.path)), "row_blocks_host_api": llh.row_blocks,
+                "device_launch": {"persistent": bool(ll_dev.persistent), "grid": ll_dev.grid, "items": ll_dev.items},
+                "bit_equal_host_vs_device_entry": bool(np.array_equal(out_h, logl_dev) and np.array_equal(out_pin, logl_dev)),
+                "parity": {"rows": int(idx.size), "max_abs_dlogL_vs_oracle": float(np.abs(logl_dev[idx] - want).max())}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,10 +302,22 @@ def main():
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer (PCIe-inclusive) passes")
     ap.add_argument("--no-strong-ref", action="store_true", help="N=1: skip the config-D-on-one-GPU reference")
     ap.add_argument("--no-model-leg", action="store_true", help="N=1: skip the model-output (reconstruct_spec) passes")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N=1: skip the legs over the other BASELINE configurations (B, E's 2048-row shard, E in full)")
+    ap.add_argument("--only-other-configs", default=None,
+                    help="diagnostic: time ONLY these legs (comma-separated: B, C, E, E2048, D) and print them as one JSON line")
     ap.add_argument("--inflight", type=int, default=1,
                     help="diagnostic: independent batches kept in flight (contexts + streams); 1 = the headline")
     args = ap.parse_args()
 
+    if args.only_other_configs:
+        legs = {}
+        for name in args.only_other_configs.split(","):
+            cfg, rows = (name[0], int(name[1:])) if len(name) > 1 else (name, None)
+            legs[name] = config_leg(cfg, rows, steps=args.steps)
+        lib = _lib.load()
+        print(json.dumps({"other_configs": legs, "library": lib.mcalf_version().decode()}))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -540,9 +628,7 @@ def main():
                     "ms_per_step_device_entry_synchronised_every_step": t_dsync / args.steps * 1e3,
                     "bit_equal_to_device_entry": same,
                     "bit_equal_to_device_entry_pinned": bool(np.array_equal(out_pin, logL_dev)),
-                    "path": {_lib.MCALF_PATH_HOST_STREAM: "one streaming launch (MCALF_PATH_HOST_STREAM)",
-                             _lib.MCALF_PATH_HOST_ZEROCOPY: "zero-copy small call, completion read off the results (MCALF_PATH_HOST_ZEROCOPY)",
-                             _lib.MCALF_PATH_HOST_PIPELINED: "row-block pipeline (MCALF_PATH_HOST_PIPELINED)"}.get(llh.path, str(llh.path)),
+                    "path": PATH_NAME.get(llh.path, str(llh.path)),
                     "stream_setup_workgroups": llh.stream_setup_wgs, "completion_polled": bool(llh.stream_polled),
                     "what": "mcalf_loglike_batch: P [batch][ndim] f64 from host memory and logL [batch] f64 back to host memory "
                             "inside every step, one synchronous call per step (SURVEY.md 8(d)); pageable numpy arrays / "
@@ -593,6 +679,7 @@ def main():
             fit.loglike_batch(PD, out=outDh)
             tDh, _ = measure(lambda: fit.loglike_batch(PD, out=outDh), kD, red_dev)
             strong_ref["host_api"] = {"ms_per_step": tDh / kD * 1e3, "host_over_device": tDh / tD,
+                                      "path": PATH_NAME.get(fit.last_launch().path, str(fit.last_launch().path)),
                                       "bit_equal_to_device_entry": bool(np.array_equal(outDh, outD.cpu().numpy()))}
         del dPD, outD
 
@@ -631,6 +718,15 @@ def main():
                      "kernel_ratio_to_logL_mode": (kmM.value / kern_ms) if nlM.value else None,
                      "logL_from_model_row0_minus_logL_entry": float(ll0 - logL_dev[0])}
         del dflux
+
+    # The other single-GPU BASELINE configurations, each both ways (device-resident / host-pointer step), on the driver's
+    # clock: B, E's per-GPU shard at N = 8 (2048 rows) and E in full (16384 rows).  (D through host pointers: the
+    # strong-scaling reference above carries it.)
+    other = None
+    if world == 1 and config == "C" and not args.no_other_configs and not args.batch and not extra:
+        other = {"B": config_leg("B", None, steps=max(20, args.steps), device=local_rank),
+                 "E_shard_2048": config_leg("E", 2048, steps=max(10, args.steps // 2), device=local_rank),
+                 "E_full_16384": config_leg("E", None, steps=max(5, args.steps // 5), device=local_rank)}
 
     out = None
     if rank == 0:
@@ -714,6 +810,16 @@ def main():
             out["strong_scaling_reference"] = strong_ref
         if model_leg:
             out["model_output"] = model_leg
+        if other:
+            if strong_ref and "host_api" in strong_ref:
+                other["D_host"] = {"workload": strong_ref["workload"], "rows": strong_ref["global_batch"],
+                                   "ms_per_step_device_resident": strong_ref["ms_per_step"],
+                                   "ms_per_step_host_api": strong_ref["host_api"]["ms_per_step"],
+                                   "host_over_device": strong_ref["host_api"]["host_over_device"],
+                                   "path_host_api": strong_ref["host_api"].get("path"),
+                                   "bit_equal_host_vs_device_entry": strong_ref["host_api"]["bit_equal_to_device_entry"]}
+            out["other_configs"] = other
+        out["library_config"] = fit.get_config()
         ll = fit.last_launch()
         out["launch"] = {"persistent": bool(ll.persistent), "grid": ll.grid, "items": ll.items,
                          "lines_per_sync": ll.lines_per_sync, "ordered_handout": bool(ll.ordered)}

@@ -31,6 +31,11 @@
  *                             the likelihood serially (PolyChord's MPI workers)
  *   mcalf_comm_* / mcalf_loglike_gather[v]_device
  *                          <- data parallelism over live points       ../cli.py:110,274-280
+ *   mcalf_create_multi, mcalf_last_launch_sub
+ *                          <- ONE process holds the whole batch       ../cli.py:274-280 (jaxns vmaps the likelihood over
+ *                             the live points inside one Python process): one context that drives several devices
+ *   mcalf_get_config       <- (none: the reference has no tunables on this path; the library says which of its own
+ *                             the loading process's environment has set)
  *
  * Ownership: the context owns all device memory it allocates.  Host pointers passed to
  * any call are borrowed for the duration of that call only.  `*_device` entries take
@@ -56,13 +61,15 @@
 extern "C" {
 #endif
 
-#define MCALF_ABI_VERSION 6   /* 2: mcalf_last_launch, gatherv / overlap / join, version string carries the source hash
+#define MCALF_ABI_VERSION 7   /* 2: mcalf_last_launch, gatherv / overlap / join, version string carries the source hash
                                  3: MCALF_PATH_HOST_STREAM, mcalf_launch_info_t grows by stream_setup_wgs / stream_polled
                                  4: mcalf_broker_serve
                                  5: mcalf_set_resident, mcalf_broker_serve_resident
                                  6: mcalf_set_cu_mask, mcalf_stream_partition, mcalf_launch_info_t grows by xcd_mask / stream_wgs_min /
                                     stream_wgs_max / stream_fallback (the streaming launch is taken only on the device shape it
-                                    was built for, and checked after every launch) */
+                                    was built for, and checked after every launch)
+                                 7: mcalf_create_multi, mcalf_last_launch_sub, mcalf_get_config; mcalf_info_t grows by ndevices /
+                                    devices[16], mcalf_launch_info_t by devices_used */
 
 enum {
     MCALF_OK = 0,
@@ -130,17 +137,35 @@ typedef struct {
     int32_t device;     /* HIP device ordinal in use                                         */
     int64_t npix;
     char arch[32];      /* gcnArchName of the device                                         */
+    int32_t ndevices;   /* device entries of the context: 1, or what mcalf_create_multi took */
+    int32_t devices[16];/* their HIP ordinals (entries may repeat)                           */
 } mcalf_info_t;
 
 /* Create / destroy.  mcalf_create never returns a half-built context: on failure *out is
  * NULL and mcalf_last_error(NULL) holds the message. */
 int mcalf_create(const mcalf_spec* spec, mcalf_ctx** out);
+/* ONE context over several devices of this process (spec->device is ignored; `devices` lists 1 .. 16 HIP ordinals, an
+ * ordinal may repeat -- two entries on one GPU are two independent sub-contexts).  The reference's large batches arise
+ * inside one process (jaxns vmaps the likelihood over the live points, cli.py:274-280): the host-pointer entries of such
+ * a context -- mcalf_loglike_batch, _chi2_batch, _model_batch, _onecomp_batch, _loglike_cube_batch -- cut the rows into
+ * contiguous blocks (rows [batch k / n, batch (k + 1) / n) to entry k of the n entries in use; an entry gets at least 256
+ * rows, so small calls and the one-theta callables run on entry 0 alone), issue every device's call concurrently -- the
+ * calling thread drives entry 0, a helper thread of the context each of the others -- and every device writes its block of
+ * results straight into the caller's array: no collective, no device-to-device traffic.  A live point's arithmetic does
+ * not depend on the shard: the results equal the single-device ones bit for bit.  mcalf_set_prior / _set_chunks /
+ * _set_cu_mask / _reserve apply to every entry, mcalf_set_resident to entry 0; the *_device entries, the profile brackets,
+ * the broker and the mcalf_comm_* family need a single-device context (MCALF_ERR_INVALID). */
+int mcalf_create_multi(const mcalf_spec* spec, const int32_t* devices, int32_t ndevices, mcalf_ctx** out);
 void mcalf_destroy(mcalf_ctx* ctx);
 int mcalf_info(const mcalf_ctx* ctx, mcalf_info_t* info);
 const char* mcalf_last_error(const mcalf_ctx* ctx);
 /* "mcalf_hip <version> (gfx950, abi <n>) src <hash>": <hash> = first 16 hex digits of the sha256 over the kernel
  * sources the library was built from ("unstamped" for a build that did not go through mc-alf_amd/build.py). */
 const char* mcalf_version(void);
+/* The configuration the context runs under, as text ("name=value ..." followed by "[env: ...]", the MCALF_* variables that
+ * were set and valid when the context was created -- the library reads its environment exactly once per context, in
+ * mcalf_create): written into buf (n bytes, always terminated; ~600 bytes suffice). */
+int mcalf_get_config(const mcalf_ctx* ctx, char* buf, int64_t n);
 
 /* Pre-size the context's device workspaces for batches up to `batch` rows so that later
  * calls (including *_device calls captured into a hipGraph) allocate nothing. */
@@ -244,8 +269,9 @@ static inline double mcalf_mailbox_call(void* box, const double* theta, int32_t 
  * for the *_device entries (the persistent fused kernel leaves no launch tail worth filling; measured) and, for
  * the host-pointer entries with large batches, ONE streaming launch (MCALF_PATH_HOST_STREAM: spectra that fit one pixel
  * tile; MCALF_STREAM=2 streams tiled ones too; an explicit block count, MCALF_STREAM=0, a tiled spectrum or a launch
- * below the persistent-grid threshold selects the row-block pipeline instead: a small first
- * block followed by larger ones, 1:1:2:4 of the rows for pageable input, 1:7 for page-locked input, so that block k+1's
+ * below the persistent-grid threshold selects the row-block pipeline instead: a first block of
+ * 128 KiB of parameter rows (MCALF_HOST_FIRST_KB; twice that for page-locked input), every following block twice the one
+ * before, the last one taking the rest, so that the GPU starts after ~10 us of staging and block k+1's staging copy,
  * H2D copy and per-sample set-up run under block k's kernel).  With more than one block in a *_device call the
  * blocks after the first run on context-owned streams between a fork event recorded on the caller's stream and
  * join events that stream waits for: the call keeps plain stream semantics (and can be captured into a
@@ -300,6 +326,7 @@ typedef struct {
     int32_t stream_fallback;/* host-pointer entries, what kept the call from being ONE streaming launch although its size asked
                                for one: 0 nothing (or not applicable), MCALF_STREAM_FALLBACK_* otherwise -- the row-block
                                pipeline (MCALF_PATH_HOST_PIPELINED) evaluated the call instead, same bits */
+    int32_t devices_used;   /* device entries the call was cut over (1 for a single-device context)                   */
 } mcalf_launch_info_t;
 enum {
     MCALF_STREAM_FALLBACK_SHAPE = 1,     /* the stream does not reach exactly the eight XCDs of an unpartitioned MI355X
@@ -309,6 +336,8 @@ enum {
                                             its rows were never evaluated, the launch's results were discarded */
 };
 int mcalf_last_launch(const mcalf_ctx* ctx, mcalf_launch_info_t* info);
+/* The same for device entry k of a multi-device context (mcalf_last_launch itself reports entry 0 and devices_used). */
+int mcalf_last_launch_sub(const mcalf_ctx* ctx, int32_t k, mcalf_launch_info_t* info);
 
 /* Restrict the context's own streams (the host-pointer entries; *_device entries run on the CALLER's stream) to the
  * compute units of `mask` -- bit i % 32 of word i / 32 = CU i in the runtime's numbering (hipExtStreamCreateWithCUMask; on a

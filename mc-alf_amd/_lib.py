@@ -63,6 +63,8 @@ class mcalf_info_t(C.Structure):
         ("device", C.c_int32),
         ("npix", C.c_int64),
         ("arch", C.c_char * 32),
+        ("ndevices", C.c_int32),
+        ("devices", C.c_int32 * 16),
     ]
 
 
@@ -89,6 +91,7 @@ class mcalf_launch_info_t(C.Structure):
         ("stream_wgs_min", C.c_int32),
         ("stream_wgs_max", C.c_int32),
         ("stream_fallback", C.c_int32),
+        ("devices_used", C.c_int32),
     ]
 
 
@@ -117,7 +120,10 @@ _PD = C.POINTER(C.c_double)
 _CTX = C.c_void_p
 SYMBOLS = {
     "mcalf_create": (C.c_int, [C.POINTER(mcalf_spec), C.POINTER(_CTX)]),
+    "mcalf_create_multi": (C.c_int, [C.POINTER(mcalf_spec), C.POINTER(C.c_int32), C.c_int32, C.POINTER(_CTX)]),
     "mcalf_destroy": (None, [_CTX]),
+    "mcalf_get_config": (C.c_int, [_CTX, C.c_char_p, C.c_int64]),
+    "mcalf_last_launch_sub": (C.c_int, [_CTX, C.c_int32, C.POINTER(mcalf_launch_info_t)]),
     "mcalf_info": (C.c_int, [_CTX, C.POINTER(mcalf_info_t)]),
     "mcalf_last_error": (C.c_char_p, [_CTX]),
     "mcalf_version": (C.c_char_p, []),

@@ -12,7 +12,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 KERNEL_SOURCE = "kernels.hip"
-HOST_SOURCES = ["host_abi.cpp", "host_stream.cpp", "broker.cpp", "comm.cpp"]
+HOST_SOURCES = ["host_abi.cpp", "host_stream.cpp", "host_config.cpp", "host_multi.cpp", "broker.cpp", "comm.cpp"]
 SOURCES = [KERNEL_SOURCE] + HOST_SOURCES
 # what the DEVICE code is made of: the kernel-source hash covers exactly these
 HASHED = ["kernels.hip", "kernel_args.h", "voigt_device.h", "voigt_tables.h"]

@@ -95,6 +95,10 @@ int resident_call(mcalf_ctx* ctx, const double* row, int rowlen, double* out) {
 extern "C" int mcalf_set_resident(mcalf_ctx* ctx, int32_t idle_us) {
     if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
     if (idle_us < 0 || idle_us > 1000000) return set_err(ctx, MCALF_ERR_INVALID, "idle limit must be 0 (off) .. 1000000 us");
+    if (is_multi(ctx)) {                                  // one-theta calls of a multi-device context go to its first device
+        const int rc = mcalf_set_resident(ctx->subs[0], idle_us);
+        return rc ? set_err(ctx, rc, "%s", ctx->subs[0]->err.c_str()) : MCALF_OK;
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (idle_us == 0) resident_stop(ctx);
     ctx->resident_us = idle_us;
@@ -130,6 +134,7 @@ extern "C" int mcalf_broker_serve(mcalf_ctx* const* ctxs, int32_t nctx, const mc
     for (int k = 0; k < nctx; ++k) {
         mcalf_ctx* c = ctxs[k];
         if (!c || c->ndim != b->ndim) return set_err(c0, MCALF_ERR_INVALID, "broker: context %d does not take rows of %d parameters", k, b->ndim);
+        MCALF_SINGLE_ONLY(c, "mcalf_broker_serve (list one single-device context per lane)");
         for (int j = 0; j < k; ++j)
             if (ctxs[j] == c) return set_err(c0, MCALF_ERR_INVALID, "broker: context %d is listed twice (a context holds one batch at a time)", k);
         HIP_TRY(c, hipSetDevice(c->device));
@@ -228,6 +233,7 @@ extern "C" int mcalf_broker_serve_resident(mcalf_ctx* ctx, void* boxes, int32_t 
     static_assert(sizeof(ResidentBox) == MCALF_MAILBOX_BYTES, "mailbox layout of include/mcalf_hip.h");
     static_assert(kResultPending == MCALF_RESULT_PENDING, "pending pattern of include/mcalf_hip.h");
     if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    MCALF_SINGLE_ONLY(ctx, "mcalf_broker_serve_resident");
     if (!boxes || !stop || slots < 1 || slots > ctx->num_cu || idle_us < 1 || idle_us > 1000000 || (reinterpret_cast<uintptr_t>(boxes) & 63))
         return set_err(ctx, MCALF_ERR_INVALID, "resident broker: 1 .. %d mailboxes (one co-resident workgroup per compute unit of this "
                        "device) at a 64-byte aligned address, idle limit 1 .. 1000000 us", ctx->num_cu);

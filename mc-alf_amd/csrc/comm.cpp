@@ -39,10 +39,10 @@ int rccl_load(mcalf_ctx* ctx) {
     void* h = nullptr;
     // MCALF_RCCL_LIB: an explicit library (tests put a two-process stand-in here to drive the N > 1 branch on a
     // one-GPU box; see tests/stubs/)
-    if (const char* over = std::getenv("MCALF_RCCL_LIB")) {
-        if (*over && !(h = dlopen(over, RTLD_NOW | RTLD_LOCAL)))
-            return set_err(ctx, MCALF_ERR_COMM, "MCALF_RCCL_LIB=%s: %s", over, dlerror());
-    }
+    // (the context's snapshot of the environment; mcalf_comm_unique_id has no context and takes one of its own)
+    const std::string over = ctx ? ctx->env.rccl_lib : read_environment().rccl_lib;
+    if (!over.empty() && !(h = dlopen(over.c_str(), RTLD_NOW | RTLD_LOCAL)))
+        return set_err(ctx, MCALF_ERR_COMM, "MCALF_RCCL_LIB=%s: %s", over.c_str(), dlerror());
     for (int i = 0; !h && i < 2; ++i)                    // a copy already in the process (torch's) wins
         h = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     for (int i = 0; !h && i < 2; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
@@ -111,6 +111,7 @@ extern "C" int mcalf_comm_unique_id(void* id128) {
 extern "C" int mcalf_comm_init(mcalf_ctx* ctx, const void* id128, int32_t nranks, int32_t rank) {
     if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks)
         return set_err(ctx, MCALF_ERR_INVALID, "mcalf_comm_init: bad arguments (nranks %d, rank %d)", nranks, rank);
+    MCALF_SINGLE_ONLY(ctx, "mcalf_comm_init (the communicator joins one process per GPU; a multi-device context needs none)");
     int rc = rccl_load(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -132,6 +133,7 @@ extern "C" int mcalf_comm_info(const mcalf_ctx* ctx, int32_t* nranks, int32_t* r
 
 extern "C" int mcalf_comm_destroy(mcalf_ctx* ctx) {
     if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    MCALF_SINGLE_ONLY(ctx, "mcalf_comm_destroy");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     comm_release(ctx);
     return MCALF_OK;
@@ -145,6 +147,7 @@ extern "C" int mcalf_comm_set_overlap(mcalf_ctx* ctx, int32_t on) {
 
 extern "C" int mcalf_comm_join(mcalf_ctx* ctx, void* stream) {
     if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
+    MCALF_SINGLE_ONLY(ctx, "mcalf_comm_join");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int k = 0; k < 2; ++k)
         if (ctx->ev_comm_used[k]) HIP_TRY(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_comm[k], 0));

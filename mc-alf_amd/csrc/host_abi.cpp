@@ -52,7 +52,7 @@ static int upload_tables(mcalf_ctx* ctx, double** d_tabs) {
 #ifndef MCALF_SRC_HASH
 #define MCALF_SRC_HASH "unstamped"      // mc-alf_amd/build.py passes the sha256 of the kernel sources
 #endif
-extern "C" const char* mcalf_version(void) { return "mcalf_hip 0.3 (gfx950, abi " MCALF_STR(MCALF_ABI_VERSION) ") src " MCALF_SRC_HASH; }
+extern "C" const char* mcalf_version(void) { return "mcalf_hip 0.4 (gfx950, abi " MCALF_STR(MCALF_ABI_VERSION) ") src " MCALF_SRC_HASH; }
 
 extern "C" const char* mcalf_last_error(const mcalf_ctx* ctx) {
     return ctx ? ctx->err.c_str() : g_last_error.c_str();
@@ -60,7 +60,15 @@ extern "C" const char* mcalf_last_error(const mcalf_ctx* ctx) {
 
 extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     if (!ctx) return;
+    if (is_multi(ctx) || ctx->pool) {                     // a multi-device parent owns its sub-contexts and workers, nothing else
+        multi_release(ctx);
+        delete ctx;
+        return;
+    }
     stream_trace_report(ctx);
+    host_trace_report(ctx);
+    for (auto& w : ctx->stagers) w->stop();
+    ctx->stagers.clear();
     (void)hipSetDevice(ctx->device);
     comm_release(ctx);
     resident_stop(ctx);
@@ -152,10 +160,7 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         return e;
     };
     ctx->lps = ((ctx->ncl_cap + 4) / 5 < (ctx->ncl_cap + 3) / 4 && ext_for(5) == ext_for(4)) ? 5 : 4;
-    if (const char* e = std::getenv("MCALF_LINES_PER_SYNC")) {
-        const int v = std::atoi(e);
-        if (v == 4 || (v == 5 && ext_for(5) == ext_for(4))) ctx->lps = v;
-    }
+    if (ctx->env.lines_per_sync == 4 || (ctx->env.lines_per_sync == 5 && ext_for(5) == ext_for(4))) ctx->lps = ctx->env.lines_per_sync;
     if (ext_for(ctx->lps) < 2 * (size_t)ctx->n_cap + 64) {
         // The LSF does not fit a workgroup tile with its halo.  numpy boundary: the fused kernel then runs without
         // convolution (a tile without halo) and the wide kernels convolve from HBM (launch_wide) -- the reference simply
@@ -309,43 +314,9 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
         if ((rc = stream_probe_xcds(ctx))) return rc;         // (the streaming launch is for one device shape only)
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_queue, kMaxChunks * sizeof(unsigned int)));
         HIP_TRY(ctx, hipMemset(ctx->d_queue, 0, kMaxChunks * sizeof(unsigned int)));
-        const char* pe = std::getenv("MCALF_PERSIST");
-        if (pe && *pe) ctx->persist = std::atoi(pe) != 0;
-        if (const char* oe = std::getenv("MCALF_ORDER")) ctx->ordered = std::atoi(oe) != 0;
-        ctx->inline_max_items = 2 * ctx->num_cu;                    // launches that fit the chip in one round of workgroups
-        if (const char* ie = std::getenv("MCALF_INLINE_MAX")) ctx->inline_max_items = std::max(0, std::atoi(ie));
-        if (const char* re = std::getenv("MCALF_RESIDENT_US")) ctx->resident_us = std::min(1000000, std::max(0, std::atoi(re)));
-        if (const char* sb = std::getenv("MCALF_SETUP_BLOCK")) {      // diagnostic: geometry of the set-up kernel
-            const int v = std::atoi(sb);
-            if (v >= 64 && v <= kSetupBlockMax && v % 64 == 0) ctx->setup_block = v;
-        }
-        if (const char* hp = std::getenv("MCALF_HOST_PLAN")) {      // e.g. "1,3,4": relative block sizes (diagnostic)
-            int n = 0;
-            for (const char* q = hp; *q && n < kMaxChunks;) {
-                const int v = std::atoi(q);
-                if (v > 0) ctx->host_plan[n++] = v;
-                while (*q && *q != ',') ++q;
-                if (*q == ',') ++q;
-            }
-            if (n > 0) ctx->host_plan_n = n;
-        }
-#ifdef MCALF_TESTING
-        if (const char* fp = std::getenv("MCALF_TEST_FAIL_PREFLIGHT")) ctx->fail_preflight = std::atoi(fp) != 0;
-#endif
-        if (const char* e = std::getenv("MCALF_STREAM")) ctx->stream_on = std::min(std::max(std::atoi(e), 0), 2);
-        if (const char* e = std::getenv("MCALF_STREAM_WGS")) ctx->stream_wgs = std::min(std::max(std::atoi(e), 1), ctx->num_cu);
-        if (const char* e = std::getenv("MCALF_STREAM_POLL")) ctx->stream_poll = std::atoi(e) != 0;
-        if (const char* e = std::getenv("MCALF_STREAM_EAGER")) ctx->stream_eager = std::max(std::atoi(e), 0);
-        if (const char* e = std::getenv("MCALF_STREAM_CHUNK")) ctx->stream_chunk = std::min(std::max(std::atoi(e) & ~7, 8), 512);
-        if (const char* e = std::getenv("MCALF_STREAM_DEVICE")) ctx->stream_device = std::atoi(e);
-        if (const char* e = std::getenv("MCALF_STREAM_TRACE")) ctx->stream_trace = std::atoi(e) != 0;
-        if (const char* e = std::getenv("MCALF_STREAM_TIMEOUT")) { const double v = std::atof(e); if (v > 0.0 && v <= 60.0) ctx->stream_timeout_s = v; }
-
-        const char* env = std::getenv("MCALF_CHUNKS");            // 0 / unset: automatic; n: exactly n row blocks
-        if (env && *env) {
-            const int v = std::atoi(env);
-            if (v >= 0 && v <= kMaxChunks) ctx->chunks_req = v;
-        }
+        // (the environment's snapshot was applied at the top of mcalf_create; what depends on the device is finished here)
+        ctx->inline_max_items = ctx->env.inline_max >= 0 ? ctx->env.inline_max : 2 * ctx->num_cu;   // launches that fit the chip in one round of workgroups
+        if (ctx->env.stream_wgs >= 0) ctx->stream_wgs = std::min(ctx->env.stream_wgs, ctx->num_cu);
     }
     return MCALF_OK;
 }
@@ -355,6 +326,8 @@ extern "C" int mcalf_create(const mcalf_spec* spec, mcalf_ctx** out) {
     *out = nullptr;
     mcalf_ctx* ctx = new (std::nothrow) mcalf_ctx();
     if (!ctx) return set_err(nullptr, MCALF_ERR_NOMEM, "out of host memory");
+    ctx->env = read_environment();                        // ONE snapshot per context; nothing else reads the environment
+    apply_environment(ctx);
     int rc = create_impl(spec, ctx);
     if (rc != MCALF_OK) {
         g_last_error = ctx->err;
@@ -378,13 +351,21 @@ extern "C" int mcalf_info(const mcalf_ctx* ctx, mcalf_info_t* info) {
     info->device = ctx->device;
     info->npix = ctx->npix;
     snprintf(info->arch, sizeof info->arch, "%s", ctx->arch.c_str());
+    info->ndevices = is_multi(ctx) ? (int32_t)ctx->subs.size() : 1;
+    for (int k = 0; k < info->ndevices && k < 16; ++k) info->devices[k] = is_multi(ctx) ? ctx->subs[k]->device : ctx->device;
     return MCALF_OK;
 }
 
 extern "C" int mcalf_last_launch(const mcalf_ctx* ctx, mcalf_launch_info_t* info) {
     if (!ctx || !info) return set_err(nullptr, MCALF_ERR_INVALID, "NULL argument");
+    if (is_multi(ctx)) {                                  // sub-context 0's launch, and how many devices the call was cut over
+        const int rc = mcalf_last_launch(ctx->subs[0], info);
+        info->devices_used = ctx->multi_last_active;
+        return rc;
+    }
     *info = ctx->last;
     info->xcd_mask = (int32_t)ctx->xcd_mask;
+    info->devices_used = 1;
     return MCALF_OK;
 }
 
@@ -401,6 +382,13 @@ extern "C" int mcalf_set_cu_mask(mcalf_ctx* ctx, const uint32_t* mask, int32_t n
     bool any = nwords == 0;
     for (int32_t i = 0; i < nwords; ++i) any = any || mask[i] != 0u;
     if (!any) return set_err(ctx, MCALF_ERR_INVALID, "CU mask selects no compute unit");
+    if (is_multi(ctx)) {
+        for (mcalf_ctx* sub : ctx->subs) {
+            const int rc = mcalf_set_cu_mask(sub, mask, nwords);
+            if (rc) return set_err(ctx, rc, "%s", sub->err.c_str());
+        }
+        return MCALF_OK;
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // the context's own streams are idle between its (synchronous) host-pointer calls; wait anyway, then replace them
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -440,6 +428,14 @@ static int grow_sample_ws(mcalf_ctx* ctx, int64_t batch) {
 
 extern "C" int mcalf_reserve(mcalf_ctx* ctx, int64_t batch) {
     if (!ctx || batch < 0) return set_err(ctx, MCALF_ERR_INVALID, "bad arguments");
+    if (is_multi(ctx)) {                                  // every device's largest shard of such a batch
+        const int n = multi_active(ctx, batch);
+        for (int k = 0; k < n; ++k) {
+            const int rc = mcalf_reserve(ctx->subs[k], (batch + n - 1) / n);
+            if (rc) return set_err(ctx, rc, "%s", ctx->subs[k]->err.c_str());
+        }
+        return MCALF_OK;
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc;
     if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, (size_t)batch * std::max(ctx->ndim, 5)))) return rc;
@@ -449,7 +445,7 @@ extern "C" int mcalf_reserve(mcalf_ctx* ctx, int64_t batch) {
     if (ctx->wide && batch > 0) {                         // the scratch of a wide-LSF launch (one pass of launch_wide)
         const int64_t rows = wide_rows_per_pass(ctx, batch);
         if (rows < 1) return set_err(ctx, MCALF_ERR_RANGE, "wide LSF: one live point exceeds the scratch of a pass");
-        const int nblocks = (int)((ctx->npix + kWideBlockThreads - 1) / kWideBlockThreads);
+        const int nblocks = (int)((ctx->npix + kWideBlockPix - 1) / kWideBlockPix);
         if ((rc = grow(ctx, &ctx->d_wide, &ctx->cap_wide, (size_t)rows * ctx->npix))) return rc;
         if ((rc = grow(ctx, &ctx->d_wtaps, &ctx->cap_wtaps, (size_t)rows * (2 * (size_t)ctx->wide_n_cap + 1)))) return rc;
         if ((rc = grow(ctx, &ctx->d_whdr, &ctx->cap_whdr, (size_t)rows))) return rc;
@@ -465,7 +461,7 @@ extern "C" int mcalf_reserve(mcalf_ctx* ctx, int64_t batch) {
 // receives the transformed rows.
 // The kernel arguments of rows [row0, row0 + nrows) of a batch (everything but the launch geometry).
 KArgs make_kargs(const mcalf_ctx* ctx, int mode, const double* dP, int64_t row0, int64_t nrows, int chunk,
-                        int targonly, int onecomp_fill, double* d_out, double* d_model, bool from_cube, double* d_theta) {
+                        int targonly, int onecomp_fill, double* d_out, double* d_model, bool from_cube, double* d_theta, int wide_stage) {
     const int rowlen = (mode == kModeOneComp) ? 5 : ctx->ndim;
     const size_t tapTotal = 2 * (size_t)ctx->n_cap + 8;
     KArgs a = {};
@@ -496,23 +492,23 @@ KArgs make_kargs(const mcalf_ctx* ctx, int mode, const double* dP, int64_t row0,
     a.nitems = (int)(nrows * ctx->ntiles);
     a.nrows = (int)nrows;
     a.queue = ctx->d_queue + chunk;
-    if (ctx->wide_stage1) {
+    if (wide_stage == kWideFused) {
         // the convolution-free fused launch of a wide-LSF context: no resolution exceeds this step (hires_fitter.py:445), the
         // continuum is 1 -- the wide kernels apply both afterwards (the layout fields startind / endind stay the context's)
         a.velstep = 1e300; a.freecont = 0; a.contval_fixed = 1.0;
-    } else if (ctx->wide) {
+    } else if (wide_stage == kWideKernels) {
         a.n_cap = ctx->wide_n_cap;                        // (arguments of the wide kernels)
     }
     return a;
 }
 
 // The finalize kernel of a tiled spectrum behind the fused kernel of `a` (adds the per-tile partials in fixed order).
-int launch_finalize(mcalf_ctx* ctx, const KArgs& a, int64_t nrows, int mode, hipStream_t stream) {
+int launch_finalize(mcalf_ctx* ctx, const KArgs& a, int64_t nrows, int mode, hipStream_t stream, int nparts) {
     const int fb = 256;
     const double* partial = a.partial;
     double* out = a.out;
     long n = (long)nrows;
-    int ntiles = ctx->ntiles, m = mode, asymm = a.asymm;
+    int ntiles = nparts > 0 ? nparts : ctx->ntiles, m = mode, asymm = a.asymm;   // (partials per live point)
     double v4 = a.veto4, v5 = a.veto5;
     void* fargs[] = {(void*)&partial, (void*)&out, (void*)&n, (void*)&ntiles, (void*)&m, (void*)&asymm, (void*)&v4, (void*)&v5};
     HIP_TRY(ctx, hipLaunchKernel(finalize_kernel_ptr(), dim3((unsigned)((nrows + fb - 1) / fb)), dim3(fb), fargs, 0, stream));
@@ -521,9 +517,9 @@ int launch_finalize(mcalf_ctx* ctx, const KArgs& a, int64_t nrows, int mode, hip
 
 static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0, int64_t nrows, int chunk,
                         int targonly, int onecomp_fill, double* d_out, double* d_model, hipStream_t stream,
-                        bool from_cube, double* d_theta, bool timed_ok) {
+                        bool from_cube, double* d_theta, bool timed_ok, int wide_stage = kWideNone) {
     const bool reduces = (mode == kModeLogL || mode == kModeChi2);
-    KArgs a = make_kargs(ctx, mode, dP, row0, nrows, chunk, targonly, onecomp_fill, d_out, d_model, from_cube, d_theta);
+    KArgs a = make_kargs(ctx, mode, dP, row0, nrows, chunk, targonly, onecomp_fill, d_out, d_model, from_cube, d_theta, wide_stage);
     // Persistent grid = the workgroup slots of the chip (2 per CU: LDS and the 4 waves per SIMD the kernel's
     // registers allow); correctness does not depend on how many of them are resident at once.  Used once every
     // slot sees at least four items: measured on MI355X, 8 items per slot (config C) -3.5 % and 160 per slot
@@ -626,7 +622,7 @@ static int launch_wide(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch
     const bool reduces = (mode == kModeLogL || mode == kModeChi2);
     const int64_t rows = wide_rows_per_pass(ctx, batch);
     if (rows < 1) return set_err(ctx, MCALF_ERR_RANGE, "wide LSF: one live point exceeds the scratch of a pass");
-    const int nblocks = (int)((npix + kWideBlockThreads - 1) / kWideBlockThreads);
+    const int nblocks = (int)((npix + kWideBlockPix - 1) / kWideBlockPix);
     int rc;
     if ((rc = launch_preflight(ctx, kModeModel, rows))) return rc;
     if ((rc = grow(ctx, &ctx->d_wide, &ctx->cap_wide, (size_t)rows * npix))) return rc;
@@ -646,13 +642,11 @@ static int launch_wide(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch
             HIP_TRY(ctx, hipLaunchKernel(wide_rows_kernel_ptr(), dim3((unsigned)((n * 5 + 255) / 256)), dim3(256), kargs, 0, stream));
             P1 = wr;
         }
-        ctx->wide_stage1 = true;
-        rc = launch_range(ctx, mode == kModeOneComp ? kModeOneComp : kModeModel, P1, 0, n, 0, targonly, onecomp_fill, nullptr, ctx->d_wide,
-                          stream, from_cube, d_theta ? d_theta + (size_t)r0 * ctx->ndim : nullptr, r0 == 0);
-        ctx->wide_stage1 = false;
-        if (rc) return rc;
+        if ((rc = launch_range(ctx, mode == kModeOneComp ? kModeOneComp : kModeModel, P1, 0, n, 0, targonly, onecomp_fill, nullptr, ctx->d_wide,
+                               stream, from_cube, d_theta ? d_theta + (size_t)r0 * ctx->ndim : nullptr, r0 == 0, kWideFused)))
+            return rc;
         KArgs a = make_kargs(ctx, mode, P0, 0, n, 0, targonly, onecomp_fill, d_out ? d_out + r0 : nullptr,
-                             d_model ? d_model + (size_t)r0 * npix : nullptr, from_cube, nullptr);
+                             d_model ? d_model + (size_t)r0 * npix : nullptr, from_cube, nullptr, kWideKernels);
         a.partial = ctx->d_wpartial;
         double* taps = ctx->d_wtaps;
         const double* taps_c = taps;
@@ -669,13 +663,7 @@ static int launch_wide(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch
             void* kargs[] = {(void*)&a, (void*)&flux, (void*)&taps_c, (void*)&stride, (void*)&hdr_c, (void*)&nb};
             HIP_TRY(ctx, hipLaunchKernel(wide_conv_kernel_ptr(), dim3((unsigned)nblocks, (unsigned)n), dim3(kWideBlockThreads), kargs, 0, stream));
         }
-        if (reduces) {
-            const int keep = ctx->ntiles;
-            ctx->ntiles = nblocks;                             // (launch_finalize adds ntiles partials per live point)
-            rc = launch_finalize(ctx, a, n, mode, stream);
-            ctx->ntiles = keep;
-            if (rc) return rc;
-        }
+        if (reduces && (rc = launch_finalize(ctx, a, n, mode, stream, nblocks))) return rc;   // (nblocks partials per live point)
     }
     return MCALF_OK;
 }
@@ -720,6 +708,7 @@ int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targon
 }
 
 extern "C" int32_t mcalf_get_chunks(const mcalf_ctx* ctx, int64_t batch) {
+    if (ctx && is_multi(ctx)) return mcalf_get_chunks(ctx->subs[0], batch);
     return (ctx && batch > 0) ? pick_chunks(ctx, batch) : 0;
 }
 
@@ -727,11 +716,13 @@ extern "C" int mcalf_set_chunks(mcalf_ctx* ctx, int32_t nchunks) {
     if (!ctx || nchunks < 0 || nchunks > kMaxChunks)
         return set_err(ctx, MCALF_ERR_INVALID, "nchunks must be 0 (automatic) .. %d", kMaxChunks);
     ctx->chunks_req = nchunks;
+    for (mcalf_ctx* sub : ctx->subs) sub->chunks_req = nchunks;
     return MCALF_OK;
 }
 
 extern "C" int mcalf_profile_begin(mcalf_ctx* ctx, int32_t max_launches) {
     if (!ctx || max_launches <= 0) return set_err(ctx, MCALF_ERR_INVALID, "bad arguments");
+    MCALF_SINGLE_ONLY(ctx, "mcalf_profile_begin");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     while (ctx->ev.size() < 2 * (size_t)max_launches) {
         hipEvent_t e;
@@ -745,6 +736,7 @@ extern "C" int mcalf_profile_begin(mcalf_ctx* ctx, int32_t max_launches) {
 
 extern "C" int mcalf_profile_end(mcalf_ctx* ctx, double* mean_ms, int32_t* launches) {
     if (!ctx || !mean_ms) return set_err(ctx, MCALF_ERR_INVALID, "bad arguments");
+    MCALF_SINGLE_ONLY(ctx, "mcalf_profile_end");
     ctx->profiling = false;
     double sum = 0.0;
     const size_t n = ctx->ev_used / 2;
@@ -763,6 +755,7 @@ extern "C" int mcalf_profile_end(mcalf_ctx* ctx, double* mean_ms, int32_t* launc
 extern "C" int mcalf_loglike_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, double* dlogL,
                                           void* stream) {
     if (!ctx || (batch > 0 && (!dP || !dlogL))) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    MCALF_SINGLE_ONLY(ctx, "mcalf_loglike_batch_device");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->last.path = MCALF_PATH_DEVICE; ctx->last.pinned_in = ctx->last.pinned_out = 0;
     return launch(ctx, kModeLogL, dP, batch, 0, 0, dlogL, nullptr, (hipStream_t)stream);
@@ -771,6 +764,7 @@ extern "C" int mcalf_loglike_batch_device(mcalf_ctx* ctx, const double* dP, int6
 extern "C" int mcalf_model_batch_device(mcalf_ctx* ctx, const double* dP, int64_t batch, int32_t targonly,
                                         double* dflux, void* stream) {
     if (!ctx || (batch > 0 && (!dP || !dflux))) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    MCALF_SINGLE_ONLY(ctx, "mcalf_model_batch_device");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->last.path = MCALF_PATH_DEVICE; ctx->last.pinned_in = ctx->last.pinned_out = 0;
     return launch(ctx, kModeModel, dP, batch, targonly ? 1 : 0, 0, nullptr, dflux, (hipStream_t)stream);
@@ -787,43 +781,94 @@ bool is_pinned_host(const void* p) {
     return at.type == hipMemoryTypeHost;
 }
 
+// MCALF_HOST_TRACE=1 (diagnostic): where a call of the row-block pipeline spends its host time, printed when the context
+// is destroyed (mean microseconds per call): staging copies by the calling thread (and the rate they ran at), copies its
+// helper took over, enqueueing (H2D commands + launches), the wait for the streams, the copy of the results.
+namespace {
+struct HostTrace { double stage_us = 0, stage_bytes = 0, helper_bytes = 0, helper_wait_us = 0, enqueue_us = 0, wait_us = 0, out_us = 0, first_enqueued_us = 0; long calls = 0, blocks = 0; };
+HostTrace g_host_trace;
+
+// The staging copy of one call, shared between the calling thread (blocks from the front, in the order the GPU wants
+// them) and the helper threads (blocks from the back): whoever claims a block copies it; `copied` says it is there.
+struct StageJob {
+    const double* src; double* dst; int rowlen; int nchunks;
+    const int64_t* bounds;
+    std::atomic<int> claim[kMaxChunks];
+    std::atomic<int> copied[kMaxChunks];
+    std::atomic<long long> helper_bytes{0};
+};
+int stage_from_back(void*, int64_t, int64_t, void* arg) {
+    StageJob* j = static_cast<StageJob*>(arg);
+    for (int c = j->nchunks - 1; c >= 1; --c) {            // (block 0 is the calling thread's: nothing may delay it)
+        int free_ = 0;
+        if (!j->claim[c].compare_exchange_strong(free_, 2)) { if (free_ == 1) break; else continue; }   // met the calling thread: done
+        const size_t off = (size_t)j->bounds[c] * j->rowlen, cnt = (size_t)(j->bounds[c + 1] - j->bounds[c]) * j->rowlen;
+        std::memcpy(j->dst + off, j->src + off, cnt * sizeof(double));
+        j->helper_bytes.fetch_add((long long)(cnt * sizeof(double)), std::memory_order_relaxed);
+        j->copied[c].store(1, std::memory_order_release);
+    }
+    return 0;
+}
+}  // namespace
+
+void host_trace_report(const mcalf_ctx* ctx) {
+    if (!ctx->host_trace || g_host_trace.calls == 0) return;
+    const HostTrace& t = g_host_trace;
+    const double n = (double)t.calls;
+    std::fprintf(stderr, "mcalf host trace (row-block pipeline, %ld calls, %.1f blocks per call; us per call): staging copy by the caller %.1f "
+                 "(%.2f GB/s), by helpers %.0f KB (waited %.1f), first block enqueued at %.1f, enqueue %.1f, wait for the streams %.1f, "
+                 "results out %.1f\n", t.calls, (double)t.blocks / n, t.stage_us / n, t.stage_us > 0 ? t.stage_bytes / t.stage_us * 1e-3 : 0.0,
+                 t.helper_bytes / n / 1024.0, t.helper_wait_us / n, t.first_enqueued_us / n, t.enqueue_us / n, t.wait_us / n, t.out_us / n);
+    g_host_trace = HostTrace();
+}
+
+// The row blocks of a pipelined host-pointer call.  The FIRST block is sized by BYTES (ctx->host_first_kb KiB of
+// parameter rows: the GPU starts after ~10 us of staging whatever the batch is -- as 1/8 of the batch, config E's first
+// block was 0.8 MB of host memcpy before the first kernel), each following block twice the one before, the last takes
+// the rest (large launches run the persistent grid and leave fewer tails).  An explicit request (mcalf_set_chunks) gives
+// equal blocks, MCALF_HOST_PLAN relative sizes.
+static int plan_row_blocks(const mcalf_ctx* ctx, int64_t batch, int rowlen, bool pin_in, int64_t* bounds) {
+    int weights[kMaxChunks];
+    int nchunks = 0;
+    if (ctx->chunks_req > 0 || ctx->host_plan_n > 0) {
+        if (ctx->chunks_req > 0) for (nchunks = 0; nchunks < ctx->chunks_req && nchunks < kMaxChunks; ++nchunks) weights[nchunks] = 1;
+        else for (nchunks = 0; nchunks < ctx->host_plan_n; ++nchunks) weights[nchunks] = ctx->host_plan[nchunks];
+        if ((int64_t)nchunks > batch) nchunks = (int)batch;
+        int total = 0, run = 0;
+        for (int c = 0; c < nchunks; ++c) total += weights[c];
+        bounds[0] = 0;
+        for (int c = 0; c < nchunks; ++c) { run += weights[c]; bounds[c + 1] = batch * run / total; }
+        return nchunks;
+    }
+    // page-locked rows need no staging copy: the first block only has to cover the latency of its own H2D command
+    int64_t first = std::max<int64_t>(64, (int64_t)ctx->host_first_kb * 1024 / ((int64_t)rowlen * (int64_t)sizeof(double)));
+    if (pin_in) first *= 2;
+    bounds[0] = 0;
+    int64_t size = first, at = 0;
+    while (nchunks < kMaxChunks - 1 && at + size + size / 2 < batch) {      // (no sliver at the end: the last block takes the rest)
+        at += size;
+        bounds[++nchunks] = at;
+        size *= 2;
+    }
+    bounds[++nchunks] = batch;
+    return nchunks;
+}
+
 // Large scalar-output batches through host pointers: the rows are cut into blocks that alternate between two
 // streams, each block being  H2D of its parameter rows -> set-up + fused kernels -> D2H of its results,  so the
 // PCIe traffic and the per-block set-up of block k+1 run under the kernels of block k.  Pageable caller memory
 // is staged through a page-locked block of the context (the host copies block k+1 in while the GPU works on
-// block k); page-locked caller memory is used by the copy engines directly.
+// block k; with MCALF_STAGE_THREADS helper threads copy the batch's last blocks meanwhile); page-locked caller memory
+// is used by the copy engines directly.
 static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly,
                               int fill, double* out_scalar) {
     int rc;
-    // Row blocks: an explicit request gives equal blocks; the automatic plan is a SMALL first block (the GPU starts
-    // after one eighth of the input has arrived) followed by larger ones (large launches run the persistent grid
-    // and leave fewer tails).  Measured on MI355X, config C (device-resident 0.251 ms per batch): pageable input
-    // 1:1:2:4 0.311 ms, 1:3:4 0.319, 2:6 0.320, four equal blocks 0.333, one block 0.351; page-locked input (no
-    // staging copy on the host thread) 1:7 0.297, 2:6 0.301, 1:1:2:4 0.307, four equal blocks 0.321.
+    const bool trace = ctx->host_trace != 0;
+    const double t_begin = trace ? now_us() : 0.0;
     const bool pin_in = is_pinned_host(P), pin_out = is_pinned_host(out_scalar);
-    int weights[kMaxChunks];
-    int nchunks = 0;
-    if (ctx->chunks_req > 0) {
-        for (nchunks = 0; nchunks < ctx->chunks_req && nchunks < kMaxChunks; ++nchunks) weights[nchunks] = 1;
-    } else if (ctx->host_plan_n > 0) {
-        for (nchunks = 0; nchunks < ctx->host_plan_n; ++nchunks) weights[nchunks] = ctx->host_plan[nchunks];
-    } else if (pin_in) {
-        weights[0] = 1; weights[1] = 7; nchunks = 2;
-    } else {
-        weights[0] = 1; weights[1] = 1; weights[2] = 2; weights[3] = 4; nchunks = 4;
-    }
-    if ((int64_t)nchunks > batch) nchunks = (int)batch;
-    if (ctx->profiling) nchunks = 1;
     int64_t bounds[kMaxChunks + 1];
-    {
-        int total = 0, run = 0;
-        for (int c = 0; c < nchunks; ++c) total += weights[c];
-        bounds[0] = 0;
-        for (int c = 0; c < nchunks; ++c) {
-            run += weights[c];
-            bounds[c + 1] = batch * run / total;
-        }
-    }
+    int nchunks = plan_row_blocks(ctx, batch, rowlen, pin_in, bounds);
+    if (ctx->profiling) { nchunks = 1; bounds[1] = batch; }
     if ((rc = ensure_aux(ctx, 1))) return rc;
     const bool reduces = (mode == kModeLogL || mode == kModeChi2);
     if (reduces && ctx->ntiles > 1 && (rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4)))
@@ -848,21 +893,48 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
     ctx->last.path = MCALF_PATH_HOST_PIPELINED; ctx->last.row_blocks = nchunks;
     ctx->last.pinned_in = pin_in ? 1 : 0; ctx->last.pinned_out = pin_out ? 1 : 0;
     hipStream_t streams[2] = {ctx->stream, ctx->aux[0]};
+    // Helpers of the staging copy (pageable rows, at least 1 MB of them): they take blocks from the back while this
+    // thread stages and enqueues from the front.
+    StageJob job;
+    int helpers = 0;
+    if (!pin_in && ctx->stage_threads > 0 && nchunks > 2 && (size_t)batch * rowlen * sizeof(double) >= ((size_t)1 << 20)) {
+        job.src = P; job.dst = stage_in; job.rowlen = rowlen; job.nchunks = nchunks; job.bounds = bounds;
+        for (int c = 0; c < kMaxChunks; ++c) { job.claim[c].store(0, std::memory_order_relaxed); job.copied[c].store(0, std::memory_order_relaxed); }
+        while ((int)ctx->stagers.size() < ctx->stage_threads) {
+            std::unique_ptr<HostWorker> w(new (std::nothrow) HostWorker());
+            if (!w) break;
+            w->start();
+            ctx->stagers.push_back(std::move(w));
+        }
+        helpers = (int)ctx->stagers.size();
+        for (int h = 0; h < helpers; ++h) ctx->stagers[h]->post(stage_from_back, &job, 0, 0);
+    }
     // A failure in block k leaves blocks < k in flight on both streams, reading the staging block / the caller's
     // page-locked rows and writing the caller's results: never return under them (the next call may free the
     // staging block, the caller its arrays).  Every error below therefore leaves through `fail`.
     hipError_t he = hipSuccess;
     const char* what = "";
     rc = MCALF_OK;
+    double t_stage = 0, t_enq = 0, t_hwait = 0, t_first = 0, stage_bytes = 0;
     for (int c = 0; c < nchunks && rc == MCALF_OK && he == hipSuccess; ++c) {
         const int64_t r0 = bounds[c], n = bounds[c + 1] - r0;
         if (n == 0) continue;
         hipStream_t st = streams[c & 1];
         const double* src = P + (size_t)r0 * rowlen;
+        const double t0 = trace ? now_us() : 0.0;
         if (!pin_in) {
-            std::memcpy(stage_in + (size_t)r0 * rowlen, src, (size_t)n * rowlen * sizeof(double));
+            int free_ = 0;
+            if (helpers == 0 || job.claim[c].compare_exchange_strong(free_, 1)) {
+                std::memcpy(stage_in + (size_t)r0 * rowlen, src, (size_t)n * rowlen * sizeof(double));
+                stage_bytes += (double)n * rowlen * sizeof(double);
+                if (trace) t_stage += now_us() - t0;
+            } else {                                      // a helper has it (or has had it): wait for its last byte
+                while (job.copied[c].load(std::memory_order_acquire) == 0) __builtin_ia32_pause();
+                if (trace) t_hwait += now_us() - t0;
+            }
             src = stage_in + (size_t)r0 * rowlen;
         }
+        const double t1 = trace ? now_us() : 0.0;
         he = hipMemcpyAsync(ctx->d_P + (size_t)r0 * rowlen, src, (size_t)n * rowlen * sizeof(double), hipMemcpyHostToDevice, st);
         if (he != hipSuccess) { what = "H2D copy of a row block"; break; }
         rc = launch_range(ctx, mode, ctx->d_P, r0, n, c, targonly, fill, d_stage_out ? d_stage_out : ctx->d_out, nullptr, st,
@@ -872,14 +944,24 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
             he = hipMemcpyAsync(stage_out + r0, ctx->d_out + r0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
             if (he != hipSuccess) { what = "D2H copy of a result block"; break; }
         }
+        if (trace) { const double t2 = now_us(); t_enq += t2 - t1; if (c == 0) t_first = t2 - t_begin; }
     }
+    for (int h = 0; h < helpers; ++h) (void)ctx->stagers[h]->wait();      // (the job lives on this frame)
+    const double t_w0 = trace ? now_us() : 0.0;
     const hipError_t s0 = hipStreamSynchronize(ctx->stream);
     const hipError_t s1 = (nchunks > 1) ? hipStreamSynchronize(ctx->aux[0]) : hipSuccess;
     if (rc != MCALF_OK) return rc;                                   // (message set by launch_range)
     if (he != hipSuccess) return set_err(ctx, MCALF_ERR_HIP, "%s failed: %s", what, hipGetErrorString(he));
     if (s0 != hipSuccess || s1 != hipSuccess)
         return set_err(ctx, MCALF_ERR_HIP, "stream synchronisation failed: %s", hipGetErrorString(s0 != hipSuccess ? s0 : s1));
+    const double t_w1 = trace ? now_us() : 0.0;
     if (!pin_out) std::memcpy(out_scalar, stage_out, (size_t)batch * sizeof(double));
+    if (trace) {
+        HostTrace& t = g_host_trace;
+        t.calls++; t.blocks += nchunks; t.stage_us += t_stage; t.stage_bytes += stage_bytes; t.helper_wait_us += t_hwait;
+        t.helper_bytes += helpers ? (double)job.helper_bytes.load() : 0.0; t.enqueue_us += t_enq; t.first_enqueued_us += t_first;
+        t.wait_us += t_w1 - t_w0; t.out_us += now_us() - t_w1;
+    }
     return MCALF_OK;
 }
 
@@ -930,11 +1012,25 @@ static int run_host_small(mcalf_ctx* ctx, int mode, const double* P, int64_t bat
 
 // Host-pointer entries: stage through the context's workspaces on its private stream.
 static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
+                    double* out_scalar, double* out_model);
+namespace {
+struct HostShard { int mode; const double* P; int rowlen, targonly, fill; double *out_scalar, *out_model; int64_t npix; };
+int host_shard(void* sub, int64_t lo, int64_t hi, void* arg) {
+    const HostShard* c = static_cast<const HostShard*>(arg);
+    return run_host(static_cast<mcalf_ctx*>(sub), c->mode, c->P + (size_t)lo * c->rowlen, hi - lo, c->rowlen, c->targonly, c->fill,
+                    c->out_scalar ? c->out_scalar + lo : nullptr, c->out_model ? c->out_model + (size_t)lo * c->npix : nullptr);
+}
+}  // namespace
+static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
                     double* out_scalar, double* out_model) {
     if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
     if (batch < 0) return set_err(ctx, MCALF_ERR_INVALID, "negative batch");
     if (batch == 0) return MCALF_OK;
     if (!P || (!out_scalar && !out_model)) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    if (is_multi(ctx)) {                                  // contiguous row blocks, one per device, straight into the caller's arrays
+        HostShard c = {mode, P, rowlen, targonly, fill, out_scalar, out_model, (int64_t)ctx->npix};
+        return multi_run(ctx, batch, host_shard, &c);
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc;
     if (out_scalar && !out_model && (size_t)batch * rowlen <= kSmallDoubles && (size_t)batch <= kSmallDoubles)
@@ -987,6 +1083,14 @@ extern "C" int mcalf_onecomp_batch(mcalf_ctx* ctx, const double* Q, int64_t batc
 extern "C" int mcalf_set_prior(mcalf_ctx* ctx, const double* lo, const double* hi, int32_t int_ncomp) {
     if (!ctx) return set_err(nullptr, MCALF_ERR_INVALID, "ctx is NULL");
     if (!lo || !hi) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    if (is_multi(ctx)) {
+        for (mcalf_ctx* sub : ctx->subs) {
+            const int rc = mcalf_set_prior(sub, lo, hi, int_ncomp);
+            if (rc) return set_err(ctx, rc, "%s", sub->err.c_str());
+        }
+        ctx->prior_set = true;
+        return MCALF_OK;
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_prior) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_prior, 2 * (size_t)ctx->ndim * sizeof(double)));
     // synchronous copies: the caller's arrays are borrowed for this call only, and a later *_device call may
@@ -1004,6 +1108,7 @@ extern "C" int mcalf_set_prior(mcalf_ctx* ctx, const double* lo, const double* h
 extern "C" int mcalf_loglike_cube_batch_device(mcalf_ctx* ctx, const double* dcube, int64_t batch, double* dtheta,
                                                double* dlogL, void* stream) {
     if (!ctx || (batch > 0 && (!dcube || !dlogL))) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    MCALF_SINGLE_ONLY(ctx, "mcalf_loglike_cube_batch_device");
     if (!ctx->prior_set) return set_err(ctx, MCALF_ERR_INVALID, "mcalf_set_prior has not been called");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->last.path = MCALF_PATH_DEVICE; ctx->last.pinned_in = ctx->last.pinned_out = 0;
@@ -1017,6 +1122,13 @@ extern "C" int mcalf_loglike_cube_batch(mcalf_ctx* ctx, const double* cube, int6
     if (!ctx->prior_set) return set_err(ctx, MCALF_ERR_INVALID, "mcalf_set_prior has not been called");
     if (batch == 0) return MCALF_OK;
     if (!cube || !logL) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    if (is_multi(ctx)) {
+        struct CubeShard { const double* cube; double *theta, *logL; int ndim; } c = {cube, theta, logL, ctx->ndim};
+        return multi_run(ctx, batch, [](void* sub, int64_t lo, int64_t hi, void* arg) {
+            const CubeShard* q = static_cast<const CubeShard*>(arg);
+            return mcalf_loglike_cube_batch(static_cast<mcalf_ctx*>(sub), q->cube + (size_t)lo * q->ndim, hi - lo, q->theta ? q->theta + (size_t)lo * q->ndim : nullptr, q->logL + lo);
+        }, &c);
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t total = (size_t)batch * ctx->ndim;
     int rc;
@@ -1050,6 +1162,7 @@ extern "C" int mcalf_scale_cube_batch(mcalf_ctx* ctx, const double* lo, const do
     if (batch < 0) return set_err(ctx, MCALF_ERR_INVALID, "negative batch");
     if (batch == 0) return MCALF_OK;
     if (!lo || !hi || !cube || !theta) return set_err(ctx, MCALF_ERR_INVALID, "NULL argument");
+    if (is_multi(ctx)) return mcalf_scale_cube_batch(ctx->subs[0], lo, hi, cube, batch, int_ncomp, theta);   // (a few bytes per row: one device)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t total = (size_t)batch * ctx->ndim;
     int rc;

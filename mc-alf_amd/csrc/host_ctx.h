@@ -6,13 +6,18 @@
 #include <rccl/rccl.h>   // types only: the library is resolved at run time (mcalf_comm_*), never linked
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #pragma GCC visibility push(default)     // the C ABI is what the library exports; everything else stays inside it
@@ -29,7 +34,99 @@ constexpr size_t kSmallDoubles = 65536;     // up to 512 KB of parameters (and a
 }  // namespace mcalf
 using namespace mcalf;
 
+// A persistent helper thread of a context (the other devices of a multi-device context: host_multi.cpp; the staging copy
+// of a large pageable batch: host_abi.cpp).  One job at a time: post(), then wait().  The thread looks for the next job
+// for a short while after one -- a sampler calls back to back -- and then sleeps on a condition variable.
+typedef int (*WorkFn)(void* who, int64_t lo, int64_t hi, void* arg);
+struct HostWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<unsigned> posted{0}, done{0};
+    bool quit = false;
+    int device = -1;                        // hipSetDevice once, when the thread starts (-1: the thread makes no HIP call)
+    void* who = nullptr;
+    WorkFn fn = nullptr;
+    void* arg = nullptr;
+    int64_t lo = 0, hi = 0;
+    int rc = 0;
+
+    void start() { th = std::thread([this] { loop(); }); }
+    void loop() {
+        if (device >= 0) (void)hipSetDevice(device);
+        unsigned seen = 0;
+        for (;;) {
+            bool got = false;
+            for (int i = 0; i < 40000 && !got; ++i) {          // ~0.2 ms of looking before the thread gives the core up
+                got = posted.load(std::memory_order_acquire) != seen;
+                if (!got) __builtin_ia32_pause();
+            }
+            if (!got) {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return quit || posted.load(std::memory_order_acquire) != seen; });
+                if (posted.load(std::memory_order_acquire) == seen) return;      // quit
+            }
+            rc = fn(who, lo, hi, arg);
+            ++seen;
+            done.store(seen, std::memory_order_release);
+        }
+    }
+    void post(WorkFn f, void* a, int64_t l, int64_t h) {
+        std::lock_guard<std::mutex> lk(m);                    // (the thread tests its predicate under this lock: no lost wake-up)
+        fn = f; arg = a; lo = l; hi = h;
+        posted.fetch_add(1, std::memory_order_release);
+        cv.notify_one();
+    }
+    int wait() {
+        const unsigned want = posted.load(std::memory_order_relaxed);
+        for (unsigned long spins = 0; done.load(std::memory_order_acquire) != want; ++spins) {
+            if ((spins & 0xFFFul) == 0xFFFul) std::this_thread::yield();
+            else __builtin_ia32_pause();
+        }
+        return rc;
+    }
+    void stop() {
+        { std::lock_guard<std::mutex> lk(m); quit = true; cv.notify_one(); }
+        if (th.joinable()) th.join();
+    }
+};
+
+// Every tunable the ENVIRONMENT of the loading process may set, read ONCE per context at the top of mcalf_create
+// (host_config.cpp: the only place the library looks at its environment).  -1 / empty = the variable is not set (or not valid): the
+// context then keeps its built-in value.  mcalf_get_config prints the EFFECTIVE values the context runs under, and which
+// of them the environment supplied, so a measured number can name its knobs.
+struct EnvKnobs {
+    int lines_per_sync = -1;                // MCALF_LINES_PER_SYNC   4 / 5
+    int persist = -1;                       // MCALF_PERSIST          0 / 1
+    int order = -1;                         // MCALF_ORDER            0 / 1
+    int inline_max = -1;                    // MCALF_INLINE_MAX       work items
+    int resident_us = -1;                   // MCALF_RESIDENT_US      0 .. 1000000
+    int setup_block = -1;                   // MCALF_SETUP_BLOCK      64 .. 512, a multiple of 64
+    int host_plan[kMaxChunks] = {};         // MCALF_HOST_PLAN        "1,3,4": relative sizes of the pipelined entry's row blocks
+    int host_plan_n = 0;
+    int host_first_kb = -1;                 // MCALF_HOST_FIRST_KB    bytes (KiB) of the pipelined entry's first row block
+    int host_trace = -1;                    // MCALF_HOST_TRACE       0 / 1: host-side time per phase of the pipelined entry
+    int stage_threads = -1;                 // MCALF_STAGE_THREADS    helper threads of the staging copy (0: the calling thread alone)
+    int stream = -1;                        // MCALF_STREAM           0 / 1 / 2
+    int stream_wgs = -1;                    // MCALF_STREAM_WGS
+    int stream_poll = -1;                   // MCALF_STREAM_POLL      0 / 1
+    int stream_eager = -1;                  // MCALF_STREAM_EAGER
+    int stream_chunk = -1;                  // MCALF_STREAM_CHUNK     8 .. 512, a multiple of 8
+    int stream_device = -1;                 // MCALF_STREAM_DEVICE    0 / 1 / 2
+    int stream_trace = -1;                  // MCALF_STREAM_TRACE     0 / 1
+    double stream_timeout_s = -1.0;         // MCALF_STREAM_TIMEOUT   seconds, (0, 60]
+    int chunks = -1;                        // MCALF_CHUNKS           0 .. 8
+    std::string rccl_lib;                   // MCALF_RCCL_LIB         (read when the first mcalf_comm_* call loads RCCL)
+#ifdef MCALF_TESTING
+    int test_fail_preflight = -1;           // MCALF_TEST_FAIL_PREFLIGHT
+    long test_xcd_mask = -1;                // MCALF_TEST_XCD_MASK
+    int test_starve = -1;                   // MCALF_TEST_STARVE
+#endif
+};
+EnvKnobs read_environment();                // host_config.cpp
+
 struct mcalf_ctx {
+    EnvKnobs env;                           // what the environment said when the context was created
     int device = 0;
     std::string arch;
     std::string err;
@@ -83,7 +180,11 @@ struct mcalf_ctx {
     // block k+1 run in the tail of block k.  chunks_req: 0 = automatic, n = exactly n blocks (1 = off).
     int chunks_req = 0;
     int host_plan[kMaxChunks] = {};            // MCALF_HOST_PLAN: relative sizes of the row blocks of the pipelined
-    int host_plan_n = 0;                       // host-pointer entry (0 = the built-in plans)
+    int host_plan_n = 0;                       // host-pointer entry (0 = the built-in plan: first block by BYTES, then doubling)
+    int host_first_kb = 128;                   // MCALF_HOST_FIRST_KB: parameter bytes (KiB) of the pipelined entry's first row block
+    int host_trace = 0;                        // MCALF_HOST_TRACE=1 (diagnostic): host-side time per phase of the pipelined entry
+    int stage_threads = 0;                     // MCALF_STAGE_THREADS: helper threads of the pageable -> page-locked staging copy
+    std::vector<std::unique_ptr<HostWorker>> stagers;   // (started by the first call that uses them)
     int num_cu = 256;
     int persist = 1;                    // fused kernel as a persistent grid (MCALF_PERSIST=0: one workgroup per item)
     int setup_block = 512;              // threads per workgroup of the set-up kernel (MCALF_SETUP_BLOCK: 64 .. 512)
@@ -142,12 +243,18 @@ struct mcalf_ctx {
     // d_wide, two more kernels do taps, periodic convolution, continuum and terms from HBM (host_abi.cpp: launch_wide).
     // n_cap is 0 for such a context (the tile carries no halo); wide_n_cap is the half-width provisioned from specres_max.
     int wide = 0, wide_n_cap = 0;
-    bool wide_stage1 = false;               // (transient: make_kargs builds the arguments of the convolution-free fused launch)
     double *d_wide = nullptr, *d_wtaps = nullptr, *d_wpartial = nullptr, *d_wrows = nullptr;
     SampleHdr* d_whdr = nullptr;
     size_t cap_wide = 0, cap_wtaps = 0, cap_wpartial = 0, cap_wrows = 0, cap_whdr = 0;
     mcalf_launch_info_t last = {};      // what the last call did (mcalf_last_launch)
+    // Single-process multi-device context (mcalf_create_multi, host_multi.cpp): the parent holds one complete context per
+    // device entry and a worker thread for each but the first; it owns no device memory itself (its problem / geometry
+    // fields are copies of sub-context 0's, for mcalf_info).
+    std::vector<mcalf_ctx*> subs;
+    struct MultiPool* pool = nullptr;
+    int multi_last_active = 0;              // sub-contexts the last call was cut over
 };
+inline bool is_multi(const mcalf_ctx* ctx) { return !ctx->subs.empty(); }
 constexpr int kCtlWords = 64, kCtlArrived = 16;
 
 // ---- host_abi.cpp ---------------------------------------------------------------------------------------------------
@@ -179,18 +286,38 @@ inline double now_us() {
 }
 
 // The kernel arguments of rows [row0, row0 + nrows) of a batch (everything but the launch geometry).
+// wide_stage (contexts whose LSF is wider than a tile, launch_wide): which of the launch's kernels the block is for
+enum { kWideNone = 0, kWideFused = 1, kWideKernels = 2 };
 KArgs make_kargs(const mcalf_ctx* ctx, int mode, const double* dP, int64_t row0, int64_t nrows, int chunk, int targonly,
-                 int onecomp_fill, double* d_out, double* d_model, bool from_cube, double* d_theta);
+                 int onecomp_fill, double* d_out, double* d_model, bool from_cube, double* d_theta, int wide_stage = kWideNone);
 // Enqueue one batch on `stream` (asynchronous): set-up kernel, fused kernel, finalize when tiled.
 int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill, double* d_out,
            double* d_model, hipStream_t stream, bool from_cube = false, double* d_theta = nullptr);
 // Everything of a launch that can fail WITHOUT anything having been enqueued (range check, workspace growth).
 int launch_preflight(mcalf_ctx* ctx, int mode, int64_t batch);
-int launch_finalize(mcalf_ctx* ctx, const KArgs& a, int64_t nrows, int mode, hipStream_t stream);
+int launch_finalize(mcalf_ctx* ctx, const KArgs& a, int64_t nrows, int mode, hipStream_t stream, int nparts = 0);
 int ensure_small(mcalf_ctx* ctx);                      // the page-locked block of small calls
 bool is_pinned_host(const void* p);
 // A stream of the context: created with the context's CU mask when it has one (mcalf_set_cu_mask).
 int create_stream(mcalf_ctx* ctx, hipStream_t* out);
+
+void apply_environment(mcalf_ctx* ctx);                // host_config.cpp: the environment's snapshot over the built-in values
+// Entries that make no sense on a multi-device parent (device pointers belong to ONE device; a communicator, a resident
+// kernel, a profile to one context) refuse it.
+#define MCALF_SINGLE_ONLY(ctx, what)                                                                              \
+    do {                                                                                                          \
+        if ((ctx) && is_multi(ctx))                                                                               \
+            return set_err(ctx, MCALF_ERR_INVALID, "%s: not available on a multi-device context (mcalf_create_multi); " \
+                           "use a single-device context per GPU", what);                                          \
+    } while (0)
+
+// ---- host_multi.cpp: one process driving several devices ---------------------------------------------------------------
+void multi_release(mcalf_ctx* ctx);                    // stops the workers, destroys the sub-contexts
+// Rows [lo, hi) of `batch` that sub-context k of n evaluates (contiguous blocks; the arithmetic of mc-alf_amd/dist.py).
+inline void multi_bounds(int64_t batch, int n, int k, int64_t* lo, int64_t* hi) { *lo = batch * k / n; *hi = batch * (k + 1) / n; }
+int multi_active(const mcalf_ctx* ctx, int64_t batch);  // sub-contexts a batch of this size is cut over (>= 1)
+// fn(sub, k, lo, hi) on every active sub-context concurrently (sub 0 on the calling thread); first error wins.
+int multi_run(mcalf_ctx* ctx, int64_t batch, WorkFn fn, void* arg);      // (fn's `who` is the sub-context)
 
 // ---- host_stream.cpp: ONE streaming launch for a large host-pointer batch ----------------------------------------------
 int stream_probe_xcds(mcalf_ctx* ctx);                 // which XCDs the context's stream reaches (ctx->xcd_mask)
@@ -202,6 +329,7 @@ void host_scale_cube(const mcalf_ctx* ctx, const double* cube, int64_t batch, do
 int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, double* out_scalar, bool* taken,
                     bool from_cube = false, double* theta_out = nullptr);
 void stream_trace_report(const mcalf_ctx* ctx);
+void host_trace_report(const mcalf_ctx* ctx);          // host_abi.cpp: MCALF_HOST_TRACE, the row-block pipeline's phases
 
 // ---- broker.cpp: resident one-theta evaluator ---------------------------------------------------------------------------
 void resident_stop(mcalf_ctx* ctx);

@@ -114,7 +114,9 @@ int stream_launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, dou
 
 bool stream_qualifies(const mcalf_ctx* ctx, int64_t batch) {
     const int64_t slots = 2LL * ctx->num_cu, nitems = batch * ctx->ntiles;
-    return ctx->persist && nitems >= 4 * slots && nitems <= 0x7fff0000LL && batch <= 0x7fff0000LL;
+    // (never a wide-LSF context: its convolution runs in the wide kernels behind a convolution-free fused launch -- the
+    // streaming workspaces and the tile's LDS carry no halo for it)
+    return !ctx->wide && ctx->persist && nitems >= 4 * slots && nitems <= 0x7fff0000LL && batch <= 0x7fff0000LL;
 }
 
 // Which XCDs do workgroups launched on the context's stream run on?  The streaming launch deals its rows to the XCDs
@@ -141,7 +143,7 @@ int stream_probe_xcds(mcalf_ctx* ctx) {
     ctx->xcd_mask = mask;
 #ifdef MCALF_TESTING
     // (test builds only: make the context BELIEVE another answer, so that the check behind every launch can be exercised)
-    if (const char* t = std::getenv("MCALF_TEST_XCD_MASK")) ctx->xcd_mask = (unsigned int)std::strtoul(t, nullptr, 0);
+    if (ctx->env.test_xcd_mask >= 0) ctx->xcd_mask = (unsigned int)ctx->env.test_xcd_mask;              // MCALF_TEST_XCD_MASK
 #endif
     return MCALF_OK;
 }
@@ -292,7 +294,7 @@ int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
 #ifdef MCALF_TESTING
     // (test builds only: pretend the kernel reported an XCD without workgroups -- no CU mask can produce one on an
     // unpartitioned device, see mcalf_set_cu_mask -- so that the path behind the report runs in a test)
-    if (const char* t = std::getenv("MCALF_TEST_STARVE")) { if (std::atoi(t) != 0) fewest = 0u; }
+    if (ctx->env.test_starve > 0) fewest = 0u;                                                          // MCALF_TEST_STARVE
 #endif
     ctx->last.stream_wgs_min = (int32_t)fewest; ctx->last.stream_wgs_max = (int32_t)ctx->h_ctl[3];
     if (gave_up != 0u || fewest == 0u) {

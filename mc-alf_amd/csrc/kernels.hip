@@ -1354,10 +1354,18 @@ __global__ void mcalf_scale_cube_kernel(const double* lo, const double* hi, cons
 // one (a very finely sampled spectrum, a very coarse resolution: the reference simply builds a longer kernel,
 // hires_fitter.py:458-464) runs the SAME fused kernel without its convolution and continuum -- the host passes it
 // velstep = 1e300 (hires_fitter.py:445: no convolution while R <= velstep), a fixed continuum of 1 -- into a buffer of
-// unconvolved spectra [rows][npix], and these two kernels do the rest from HBM: the taps of every live point (any half-width
-// up to the one provisioned from specres_max), then the periodic convolution, the continuum and the likelihood terms.
-// Rare path, written for clarity: one weight and one flux load per FMA.
+// unconvolved spectra [rows][npix], and these two kernels do the rest: the taps of every live point (any half-width up
+// to the one provisioned from specres_max), then the periodic convolution, the continuum and the likelihood terms.
+// The convolution is the fused kernel's scheme at a larger scale: a workgroup owns kWideBlockPix consecutive outputs,
+// eight per thread, and walks over the taps in passes of kWideTapChunk -- per pass the flux window (outputs + taps of the
+// pass, wrapped round the spectrum as often as it takes) and the taps are staged in LDS, the window in the mod-8 planar
+// layout, and every thread slides an 8-register window over it: one LDS flux read and one broadcast weight per 8 FMAs.
+// Every output accumulates its taps in tap order (tap 0 first), which is astropy's loop order and the order `bot` is
+// formed in -- an absorber-free model therefore comes out as exactly 1.0, as it does from the fused kernel.
 constexpr int kWideBlock = kWideBlockThreads;
+constexpr int kWidePlane = (kWideBlockPix + kWideTapChunk + 16) / 8 + 2;      // 324: plane stride of the staged window
+static_assert(kWideBlockPix == 8 * kWideBlock && kWideTapChunk % 8 == 0 && kWidePlane % 32 == 4, "wide convolution geometry");
+__device__ __forceinline__ int wide_pos(int i) { return (i & 7) * kWidePlane + (i >> 3); }
 __device__ __forceinline__ double wide_block_sum(double v, double* red, int tid) {      // fixed order (deterministic)
     v = wave_sum(v);
     if ((tid & 63) == 0) red[tid >> 6] = v;
@@ -1379,7 +1387,8 @@ __device__ __forceinline__ void wide_decode(const KArgs& a, long s, double& R, d
 }
 
 // One workgroup per live point: its normalised Gaussian taps w[0 .. 2n] (astropy's Gaussian1DKernel divided by its sum),
-// the sum `bot` astropy's loop divides by, and the header (continuum, bot, n, bad).  Sums in fixed order.
+// the sum `bot` astropy's loop divides by -- added up tap after tap, tap 0 first, the order the convolution's numerator
+// chain runs in (as setup_sample() does for the fused kernel) -- and the header (continuum, bot, n, bad).
 __global__ __launch_bounds__(kWideBlock) void mcalf_wide_taps_kernel(const KArgs a, double* taps, long tap_stride, SampleHdr* hdr) {
     __shared__ double red[kWideBlock / 64];
     const long s = blockIdx.x;
@@ -1404,61 +1413,107 @@ __global__ __launch_bounds__(kWideBlock) void mcalf_wide_taps_kernel(const KArgs
         part += g;
     }
     const double gsum = wide_block_sum(part, red, tid);
-    part = 0.0;
-    for (long k = tid; k <= 2 * n; k += kWideBlock) {
-        const double v = w[k] / gsum;                            // normalize_kernel=True
-        w[k] = v;
-        part += v;
-    }
-    const double bot = wide_block_sum(part, red, tid);
+    for (long k = tid; k <= 2 * n; k += kWideBlock) w[k] = w[k] / gsum;     // normalize_kernel=True
+    __threadfence_block();
+    __syncthreads();
     if (tid == 0) {
+        double bot = 0.0;                                        // tap order: a dependent chain of 2n + 1 additions, once per live point
+        for (long k = 0; k <= 2 * n; ++k) bot += w[k];
         SampleHdr h;
         h.cont = cont; h.bot = bot; h.ncl = 0; h.n = (int)n; h.bad = bad ? 1 : 0; h.ngeneral = 0;
         hdr[s] = h;
     }
 }
 
-// Workgroup (blockIdx.x, blockIdx.y) = pixels [256 x, 256 x + 256) of live point y:  model = (sum_k w_k flux[(i + k - n) mod
+// Workgroup (blockIdx.x, blockIdx.y) = pixels [2048 x, 2048 x + 2048) of live point y:  model = (sum_k w_k flux[(i + k - n) mod
 // npix]) / bot x continuum (astropy boundary='wrap', taps in window order; hires_fitter.py:463-464, :447), then the model
 // row and / or the likelihood terms (:292-303) summed over the block into partial[y][x][4], which mcalf_finalize_kernel adds up.
 __global__ __launch_bounds__(kWideBlock) void mcalf_wide_conv_kernel(const KArgs a, const double* flux, const double* taps, long tap_stride,
                                                                          const SampleHdr* hdr, int nblocks) {
     __shared__ double red[kWideBlock / 64];
+    __shared__ double sF[8 * kWidePlane];
+    __shared__ double sW[kWideTapChunk];
     const long s = blockIdx.y;
     const int tid = threadIdx.x;
-    const long i = (long)blockIdx.x * kWideBlock + tid;
+    const long i0 = (long)blockIdx.x * kWideBlockPix;            // first output pixel of the workgroup
     const SampleHdr h = hdr[s];
-    const long n = h.n, npix = a.npix;
+    const long n = h.n, npix = a.npix, ntaps = 2 * n + 1;
     const double* f = flux + (size_t)s * npix;
     const double* w = taps + (size_t)s * tap_stride;
-    const bool live = i < npix;
-    double mval = NAN;
-    if (live && !h.bad) {
-        long idx = (i - n) % npix;
-        if (idx < 0) idx += npix;
-        double top = 0.0;
-        for (long k = 0; k <= 2 * n; ++k) {
-            top = fma(f[idx], w[k], top);
-            if (++idx == npix) idx = 0;
+    double top[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) top[m] = 0.0;
+    if (!h.bad) {                                                // (workgroup-uniform)
+        for (long k0 = 0; k0 < ntaps; k0 += kWideTapChunk) {
+            const int kt = (int)min((long)kWideTapChunk, ntaps - k0);       // taps of this pass
+            // window element e of the pass = flux[(i0 - n + k0 + e) mod npix]: output 8 t + m reads element 8 t + m + k at tap k0 + k
+            long src = (i0 - n + k0 + tid) % npix;
+            if (src < 0) src += npix;
+            const long step = kWideBlock % npix;
+            for (int e = tid; e < kWideBlockPix + kWideTapChunk + 16; e += kWideBlock) {
+                sF[wide_pos(e)] = (e < kWideBlockPix + kt) ? f[src] : 0.0;   // (past the pass's window: never multiplied by a tap)
+                src += step;
+                if (src >= npix) src -= npix;
+            }
+            for (int k = tid; k < kWideTapChunk; k += kWideBlock) sW[k] = (k < kt) ? w[k0 + k] : 0.0;
+            __syncthreads();
+            double win[8];
+            const double* fp = sF + tid;                         // element 8 tid + 8 c + r  ->  fp[r * kWidePlane + c]
+#pragma unroll
+            for (int m = 0; m < 8; ++m) win[m] = fp[m * kWidePlane];
+            const double* wp = sW;
+            for (int q0 = 0; q0 + 8 <= kt; q0 += 8) {            // whole groups of eight taps
+                ++fp;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const double wgt = wp[r];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) top[m] = fma(win[(m + r) & 7], wgt, top[m]);
+                    win[r] = fp[r * kWidePlane];
+                }
+                wp += 8;
+            }
+            {                                                    // the pass's last 0..7 taps: no zero-weight padding taps
+                const int rem = kt & 7;                          // (workgroup-uniform)
+                ++fp;
+#pragma unroll
+                for (int r = 0; r < 7; ++r) {
+                    if (r >= rem) break;
+                    const double wgt = wp[r];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) top[m] = fma(win[(m + r) & 7], wgt, top[m]);
+                    win[r] = fp[r * kWidePlane];
+                }
+            }
+            __syncthreads();                                     // every wave is past its reads before the next pass overwrites
         }
-        mval = top / h.bot;
-        mval *= h.cont;                                          // :447
     }
-    if (a.model && live) a.model[(size_t)s * npix + i] = mval;
-    if (a.mode != kModeLogL && a.mode != kModeChi2) return;     // (workgroup-uniform)
+    const bool reduces = a.mode == kModeLogL || a.mode == kModeChi2;
     double acc = 0.0, nnz = 0.0, c4 = 0.0, c5 = 0.0;
-    if (live) {
-        const double d = a.obj[i] - mval;
-        double term = a.ispec2[i] * (d * d);
-        if (a.mode == kModeLogL) term = (term - a.lgis[i]) + a.log2pi;      // :294
-        if (!isnan(term)) acc = term;                                     // np.nansum
-        if (a.mode == kModeChi2 && mval != 0.0) nnz = 1.0;                // :241
-        if (a.asymm) {                                                     // :298-302
-            const double resid = d / a.err[i];
-            if (resid > 4.0) c4 = 1.0;
-            if (resid > 5.0) c5 = 1.0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const long i = i0 + 8 * tid + m;
+        if (i >= npix) break;
+        double mval = NAN;
+        if (!h.bad) {
+            mval = top[m] / h.bot;
+            mval *= h.cont;                                      // :447
+        }
+        if (a.model) a.model[(size_t)s * npix + i] = mval;
+        if (reduces) {
+            const double d = a.obj[i] - mval;
+            double term = a.ispec2[i] * (d * d);
+            if (a.mode == kModeLogL) term = (term - a.lgis[i]) + a.log2pi;      // :294
+            if (!isnan(term)) acc += term;                                    // np.nansum
+            if (a.mode == kModeChi2 && mval != 0.0) nnz += 1.0;               // :241
+            if (a.asymm) {                                                     // :298-302
+                const double resid = d / a.err[i];
+                if (resid > 4.0) c4 += 1.0;
+                if (resid > 5.0) c5 += 1.0;
+            }
         }
     }
+    if (!reduces) return;                                        // (workgroup-uniform)
     acc = wide_block_sum(acc, red, tid);
     nnz = wide_block_sum(nnz, red, tid);
     if (a.asymm) { c4 = wide_block_sum(c4, red, tid); c5 = wide_block_sum(c5, red, tid); }

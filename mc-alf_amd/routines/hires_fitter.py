@@ -107,8 +107,10 @@ class als_fitter:
 
     Extra keywords (all optional): `spectrum=(wl, flux, err)` arrays instead of a file;
     `linepars=[(wrest, f, gamma), ...]` instead of a linetools lookup; `velstep=`;
-    `conv_mode='numpy'|'jax'`; `device=` HIP ordinal; `gauss_cdf=[n3, n4, n5]` to pin the
-    asymmetric-veto thresholds the reference draws at random.
+    `conv_mode='numpy'|'jax'`; `device=` HIP ordinal, or a LIST of ordinals for one context that drives
+    several GPUs of this process (`mcalf_create_multi`: the batched entries cut their rows into contiguous
+    blocks, one per device, results bit-identical to one device; entries may repeat);
+    `gauss_cdf=[n3, n4, n5]` to pin the asymmetric-veto thresholds the reference draws at random.
     """
 
     def __init__(self, specfile, fitrange, fitlines, ncomp, nfill=0, specres=[7.0], contval=[1.0],
@@ -241,12 +243,16 @@ class als_fitter:
         sp.specres_max = float(self.specres[1]) if (jax and self.freespecres) else float(max(self.specres))
         sp.contval_fixed = float(self.contval[0])
         sp.conv_mode = _lib.MCALF_CONV_SAME_EDGE_JAX if jax else _lib.MCALF_CONV_WRAP_NUMPY
-        sp.device = int(device)
+        devices = None if np.ndim(device) == 0 else [int(d) for d in device]
+        sp.device = int(device) if devices is None else devices[0]
         sp.asymmlike = int(bool(self.Asymmlike))
         sp.asymm_n4 = float(self.gauss_cdf[1])
         sp.asymm_n5 = float(self.gauss_cdf[2])
         ctx = C.c_void_p()
-        _lib.check(lib.mcalf_create(C.byref(sp), C.byref(ctx)))
+        if devices is None:
+            _lib.check(lib.mcalf_create(C.byref(sp), C.byref(ctx)))
+        else:
+            _lib.check(lib.mcalf_create_multi(C.byref(sp), (C.c_int32 * len(devices))(*devices), len(devices), C.byref(ctx)))
         self._ctx = ctx
         self._lib = lib
         info = _lib.mcalf_info_t()
@@ -301,12 +307,22 @@ class als_fitter:
         ptr = words.ctypes.data_as(C.POINTER(C.c_uint32)) if words.size else None
         _lib.check(self._lib.mcalf_set_cu_mask(self._ctx, ptr, int(words.size)), self._ctx)
 
-    def last_launch(self):
+    def last_launch(self, sub=None):
         """What the last call of this context did (`mcalf_last_launch`): entry plan, row blocks, whether the fused
-        kernel ran as the persistent grid, its grid and work-item count."""
+        kernel ran as the persistent grid, its grid and work-item count, the device entries it was cut over.
+        `sub=k`: device entry k of a multi-device context (`mcalf_last_launch_sub`)."""
         info = _lib.mcalf_launch_info_t()
-        _lib.check(self._lib.mcalf_last_launch(self._ctx, C.byref(info)), self._ctx)
+        if sub is None:
+            _lib.check(self._lib.mcalf_last_launch(self._ctx, C.byref(info)), self._ctx)
+        else:
+            _lib.check(self._lib.mcalf_last_launch_sub(self._ctx, int(sub), C.byref(info)), self._ctx)
         return info
+
+    def get_config(self):
+        """The knobs the context runs under and the MCALF_* variables its environment had set (`mcalf_get_config`)."""
+        buf = C.create_string_buffer(2048)
+        _lib.check(self._lib.mcalf_get_config(self._ctx, buf, len(buf)), self._ctx)
+        return buf.value.decode()
 
     def __del__(self):
         try:

@@ -37,9 +37,9 @@ def test_library_exports_every_symbol():
 def test_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.mcalf_line) == 24
     assert C.sizeof(_lib.mcalf_spec) == 8 + 3 * 8 + 8 + 8 + 8 + 24 + 4 * 4 + 3 * 8 + 2 * 4 + 8 + 2 * 8
-    assert C.sizeof(_lib.mcalf_info_t) == 8 * 4 + 8 + 32
+    assert C.sizeof(_lib.mcalf_info_t) == 8 * 4 + 8 + 32 + 4 + 16 * 4 + 4          # (ABI 7: ndevices, devices[16]; padded to 8)
     assert C.sizeof(_lib.mcalf_broker_t) == 2 * 4 + 10 * 8
-    assert C.sizeof(_lib.mcalf_launch_info_t) == 4 * 4 + 8 + 12 * 4 == 72
+    assert C.sizeof(_lib.mcalf_launch_info_t) == 4 * 4 + 8 + 13 * 4 + 4 == 80            # (ABI 7: devices_used; padded to 8)
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -115,6 +115,18 @@ def test_null_arguments_do_not_crash():
     assert lib.mcalf_voigt_hjerting(None, None, 0, None, -1) == 0
     assert lib.mcalf_set_cu_mask(None, None, 0) == -1
     assert lib.mcalf_stream_partition(8, 0, None, None) == -1 and lib.mcalf_stream_partition(8, 4, None, None) == -1
+    assert lib.mcalf_get_config(None, None, 0) == -1 and lib.mcalf_last_launch_sub(None, 0, None) == -1
+    assert lib.mcalf_create_multi(None, None, 0, C.byref(ctx)) == -1 and not ctx.value
+    sp, keep = _spec()
+    assert lib.mcalf_create_multi(C.byref(sp), (C.c_int32 * 1)(0), 17, C.byref(ctx)) == -1 and not ctx.value    # 1 .. 16 entries
+
+
+def test_the_environment_is_read_in_one_place():
+    """One configuration object instead of getenv calls scattered over the library: host_config.cpp takes ONE snapshot
+    per context (read_environment, called from mcalf_create) and mcalf_get_config prints what the context runs under."""
+    csrc = os.path.join(ROOT, "mc-alf_amd", "csrc")
+    users = sorted(f for f in os.listdir(csrc) if f.endswith((".cpp", ".hip", ".h")) and "getenv" in open(os.path.join(csrc, f)).read())
+    assert users == ["host_config.cpp"], users
 
 
 def test_product_library_carries_no_failure_injection_hooks():

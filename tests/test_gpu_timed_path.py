@@ -84,6 +84,26 @@ def test_config_e_per_gpu_shard_through_the_device_entry_against_both_oracles():
     assert np.abs(got[idx] - o.loglike_batch(prob, P[idx])).max() < LOGL_ATOL
 
 
+def test_config_e_full_batch_every_row_against_the_c_oracle():
+    """BASELINE config E at FULL size: all 16384 rows of `default_rng(4)` through the device entry (ONE persistent launch
+    over 16384 x 5 pixel tiles) and through the host-pointer entry, every row against the C oracle (16 threads, ~20 s):
+    |dlogL| < 1e-4 absolute (north_star) and 1e-10 relative; the two entries agree bit for bit."""
+    kw, batch, seed = workloads.config("E", oracle_synth)
+    P = workloads.draw_P(kw, batch, np.random.default_rng(seed), damped=2)
+    prob = problem_from_kwargs(kw)
+    dP = torch.from_numpy(P).cuda()
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        got = _device_logl(fit, dP, batch)
+        ll = fit.last_launch()
+        assert (ll.path, ll.row_blocks, ll.persistent, ll.items) == (_lib.MCALF_PATH_DEVICE, 1, 1, 5 * batch)
+        host = fit.loglike_batch(P)
+        assert fit.last_launch().path in (_lib.MCALF_PATH_HOST_PIPELINED, _lib.MCALF_PATH_HOST_STREAM)
+    assert np.isfinite(got).all() and np.array_equal(host, got)
+    want = c_oracle.COracle(prob, threads=min(16, os.cpu_count() or 1)).loglike_batch(P)        # EVERY row
+    assert np.abs(got - want).max() < LOGL_ATOL
+    assert (np.abs(got - want) / np.abs(want)).max() < 1e-10
+
+
 def test_jax_semantics_persistent_launch_against_the_f64_restatement():
     """conv_mode='jax' (hires_fitter.py:521-695: fixed kernel grid, zero padding, edge reset, floor on the ncomp slot) on
     config C with 2600 rows through the device entry -- the persistent `<true, ...>` instantiation a vectorised jaxns
@@ -177,13 +197,14 @@ def test_pipelined_host_entry_is_the_path_taken_and_is_bit_equal(monkeypatch):
         assert nsmall * P.shape[1] > 65536
         assert np.array_equal(fit.loglike_batch(P[:nsmall]), whole[:nsmall])
         ll = fit.last_launch()
-        assert (ll.path, ll.row_blocks) == (_lib.MCALF_PATH_HOST_PIPELINED, 4)
-    # the row-block pipeline as the default plan (MCALF_STREAM=0): 1 : 1 : 2 : 4 pageable, 1 : 7 page-locked
+        assert (ll.path, ll.row_blocks) == (_lib.MCALF_PATH_HOST_PIPELINED, 3)
+    # the row-block pipeline as the default plan (MCALF_STREAM=0): a first block of 128 KiB of rows (348 of these), then
+    # doubling, the last block takes the rest -- 348 + 696 + 1556 pageable; twice the first block page-locked: 696 + 1904
     monkeypatch.setenv("MCALF_STREAM", "0")
     with mcalf_amd.als_fitter(None, **kw) as fit:
         assert np.array_equal(fit.loglike_batch(P), whole)
         ll = fit.last_launch()
-        assert (ll.path, ll.row_blocks, ll.pinned_in) == (_lib.MCALF_PATH_HOST_PIPELINED, 4, 0)
+        assert (ll.path, ll.row_blocks, ll.pinned_in) == (_lib.MCALF_PATH_HOST_PIPELINED, 3, 0)
         opin = torch.full((n,), float("nan"), dtype=torch.float64).pin_memory().numpy()
         fit.loglike_batch(Ppin, out=opin)
         ll = fit.last_launch()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: the measurement / verification recipes of a round, ONE parameterised script (run through gpurun from the repo
-# root; everything lands under gpurun_out/<tag>/).   tools/gpu_session.sh <recipe> [tag, default r05] [args]
+# root; everything lands under gpurun_out/<tag>/).   tools/gpu_session.sh <recipe> [tag, default r06] [args]
 #   tests              the whole `-m gpu` suite in one process
 #   bench [cfg]        the driver's bench line (default config C) + the same under rocprofv3 --kernel-trace --stats
 #   profiles <cfg>     tools/profiles.sh: bench line, kernel trace, PMC passes, issue rates, bench line WITH counters
@@ -11,7 +11,10 @@
 #   dropin             tools/dropin_ranks.py: ranks with a context each, ranks behind the broker
 #   hostfloor          tools/host_floor.py: what a synchronous host-pointer step costs at best
 #   ab <cfg> [steps]   tools/abl_bench.sh over build/abl/lib_*.so
-recipe=${1:-tests}; tag=${2:-r05}; shift 2 2>/dev/null
+#   hostgap [legs]     the host-pointer step against the device-resident one (bench.py --only-other-configs) under the
+#                      default plan and its alternatives, interleaved twice: old 1:1:2:4 plan, streaming launch for tiled
+#                      spectra, a staging helper thread, the one-launch variant for two rounds of workgroups
+recipe=${1:-tests}; tag=${2:-r06}; shift 2 2>/dev/null
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/$tag; mkdir -p "$out" build
 case "$recipe" in
@@ -58,5 +61,34 @@ PY
   ab)
     cfg=${1:-C}; steps=${2:-200}
     ABL_ROUNDS=${ABL_ROUNDS:-3} bash tools/abl_bench.sh --config $cfg --no-model-leg --steps $steps > "$out/ab_$cfg.txt" 2>&1; cat "$out/ab_$cfg.txt" ;;
+  hostgap)
+    legs=${1:-B,E,E2048}
+    run() {  # name, then VAR=value ...
+      name=$1; shift
+      env "$@" MCALF_HOST_TRACE=1 MCALF_STREAM_TRACE=1 timeout -k 10 300 python3 bench.py --only-other-configs $legs --steps 20 > "$out/hostgap_$name.json" 2> "$out/hostgap_$name.err"
+      python3 - "$out/hostgap_$name.json" "$name" <<'PY' | tee -a "$out/hostgap.txt"
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])["other_configs"]
+except Exception as exc:
+    print(sys.argv[2], "FAILED", exc); raise SystemExit(0)
+for k, v in d.items():
+    print("%-22s %-6s device %.4f  host %.4f (x %.3f)  pinned %.4f (x %.3f)  %s, %d blocks, bits %s, parity %.1e" % (
+        sys.argv[2], k, v["ms_per_step_device_resident"], v["ms_per_step_host_api"], v["host_over_device"], v["ms_per_step_host_api_pinned"],
+        v["host_over_device_pinned"], v["path_host_api"].split("(")[1].rstrip(")"), v["row_blocks_host_api"], v["bit_equal_host_vs_device_entry"],
+        v["parity"]["max_abs_dlogL_vs_oracle"]))
+PY
+      grep -h "mcalf .* trace" "$out/hostgap_$name.err" | sed "s/^/    $name: /" >> "$out/hostgap.txt"
+    }
+    : > "$out/hostgap.txt"
+    for round in 1 2; do
+      run default_$round A=0
+      run oldplan_$round MCALF_HOST_PLAN=1,1,2,4
+      run stream2_$round MCALF_STREAM=2
+      run helper1_$round MCALF_STAGE_THREADS=1
+      run helper2_$round MCALF_STAGE_THREADS=2
+      run inline1024_$round MCALF_INLINE_MAX=1024
+    done
+    cat "$out/hostgap.txt" ;;
   *) echo "unknown recipe $recipe"; exit 2 ;;
 esac
