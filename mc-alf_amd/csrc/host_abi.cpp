@@ -85,6 +85,8 @@ extern "C" void mcalf_destroy(mcalf_ctx* ctx) {
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (hipEvent_t e : ctx->ev_h2d)
+        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_join)
         if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : ctx->aux)
@@ -503,14 +505,19 @@ KArgs make_kargs(const mcalf_ctx* ctx, int mode, const double* dP, int64_t row0,
 }
 
 // The finalize kernel of a tiled spectrum behind the fused kernel of `a` (adds the per-tile partials in fixed order).
-int launch_finalize(mcalf_ctx* ctx, const KArgs& a, int64_t nrows, int mode, hipStream_t stream, int nparts) {
+int launch_finalize(mcalf_ctx* ctx, const KArgs& a, int64_t nrows, int mode, hipStream_t stream, int nparts, bool signal) {
     const int fb = 256;
     const double* partial = a.partial;
     double* out = a.out;
     long n = (long)nrows;
     int ntiles = nparts > 0 ? nparts : ctx->ntiles, m = mode, asymm = a.asymm;   // (partials per live point)
     double v4 = a.veto4, v5 = a.veto5;
-    void* fargs[] = {(void*)&partial, (void*)&out, (void*)&n, (void*)&ntiles, (void*)&m, (void*)&asymm, (void*)&v4, (void*)&v5};
+    // signal: the streaming launch of a tiled spectrum -- the kernel tells the host (h_ctl[kCtlFinalized] = the launch's stamp)
+    unsigned int* fin_count = signal ? &ctx->d_sctl->fin_exited : nullptr;
+    unsigned int* done_word = signal ? ctx->d_ctl + kCtlFinalized : nullptr;
+    unsigned int gen = ctx->stream_gen;
+    void* fargs[] = {(void*)&partial, (void*)&out, (void*)&n, (void*)&ntiles, (void*)&m, (void*)&asymm, (void*)&v4, (void*)&v5,
+                     (void*)&fin_count, (void*)&done_word, (void*)&gen};
     HIP_TRY(ctx, hipLaunchKernel(finalize_kernel_ptr(), dim3((unsigned)((nrows + fb - 1) / fb)), dim3(fb), fargs, 0, stream));
     return MCALF_OK;
 }
@@ -787,6 +794,10 @@ bool is_pinned_host(const void* p) {
 namespace {
 struct HostTrace { double stage_us = 0, stage_bytes = 0, helper_bytes = 0, helper_wait_us = 0, enqueue_us = 0, wait_us = 0, out_us = 0, first_enqueued_us = 0; long calls = 0, blocks = 0; };
 HostTrace g_host_trace;
+// MCALF_HOST_TRACE=2: additionally the GPU-side timeline of the LAST pipelined call -- per row block the times (us after the
+// call began) at which its H2D copy started and ended and its kernels ended on the device, and when the host enqueued it
+struct BlockTimeline { int n = 0; long rows[kMaxChunks]; float h2d0[kMaxChunks], h2d1[kMaxChunks], done[kMaxChunks]; double host_enq[kMaxChunks]; int pinned = 0; };
+BlockTimeline g_block_timeline;
 
 // The staging copy of one call, shared between the calling thread (blocks from the front, in the order the GPU wants
 // them) and the helper threads (blocks from the back): whoever claims a block copies it; `copied` says it is there.
@@ -820,6 +831,11 @@ void host_trace_report(const mcalf_ctx* ctx) {
                  "results out %.1f\n", t.calls, (double)t.blocks / n, t.stage_us / n, t.stage_us > 0 ? t.stage_bytes / t.stage_us * 1e-3 : 0.0,
                  t.helper_bytes / n / 1024.0, t.helper_wait_us / n, t.first_enqueued_us / n, t.enqueue_us / n, t.wait_us / n, t.out_us / n);
     g_host_trace = HostTrace();
+    const BlockTimeline& b = g_block_timeline;
+    for (int c = 0; c < b.n; ++c)
+        std::fprintf(stderr, "mcalf host trace, last call (%s rows), block %d: %ld rows, enqueued by the host at %.1f us; on the device: H2D %.1f .. %.1f, "
+                     "kernels done %.1f\n", b.pinned ? "page-locked" : "pageable", c, b.rows[c], b.host_enq[c], b.h2d0[c] * 1e3, b.h2d1[c] * 1e3, b.done[c] * 1e3);
+    g_block_timeline = BlockTimeline();
 }
 
 // The row blocks of a pipelined host-pointer call.  The FIRST block is sized by BYTES (ctx->host_first_kb KiB of
@@ -854,9 +870,12 @@ static int plan_row_blocks(const mcalf_ctx* ctx, int64_t batch, int rowlen, bool
     return nchunks;
 }
 
-// Large scalar-output batches through host pointers: the rows are cut into blocks that alternate between two
-// streams, each block being  H2D of its parameter rows -> set-up + fused kernels -> D2H of its results,  so the
-// PCIe traffic and the per-block set-up of block k+1 run under the kernels of block k.  Pageable caller memory
+// Large scalar-output batches through host pointers: the rows are cut into blocks; the H2D copies of ALL blocks go to a
+// copy stream of their own, one behind the other as the host stages them, and block k's kernels (set-up + fused, on two
+// alternating streams) wait for the event behind its copy -- so block k+1's rows are in HBM long before block k's kernels
+// end, and its set-up runs in their tail.  (Round 5 queued every block's copy on the block's own stream: the copy of
+// block k+2 then waited for the kernels of block k, and the GPU idled for the copy + set-up at every second block
+// boundary -- measured with MCALF_HOST_TRACE=2, profiles/r06_pipeline_timeline.txt.)  Pageable caller memory
 // is staged through a page-locked block of the context (the host copies block k+1 in while the GPU works on
 // block k; with MCALF_STAGE_THREADS helper threads copy the batch's last blocks meanwhile); page-locked caller memory
 // is used by the copy engines directly.
@@ -869,7 +888,9 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
     int64_t bounds[kMaxChunks + 1];
     int nchunks = plan_row_blocks(ctx, batch, rowlen, pin_in, bounds);
     if (ctx->profiling) { nchunks = 1; bounds[1] = batch; }
-    if ((rc = ensure_aux(ctx, 1))) return rc;
+    if ((rc = ensure_aux(ctx, 2))) return rc;
+    for (hipEvent_t& e : ctx->ev_h2d)
+        if (!e) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const bool reduces = (mode == kModeLogL || mode == kModeChi2);
     if (reduces && ctx->ntiles > 1 && (rc = grow(ctx, &ctx->d_partial, &ctx->cap_partial, (size_t)batch * ctx->ntiles * 4)))
         return rc;
@@ -882,6 +903,7 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
         ctx->cap_stage = need;
     }
     double* stage_in = pin_in ? nullptr : ctx->h_stage;
+    hipStream_t copy_stream = ctx->aux[1];
     double* stage_out = pin_out ? out_scalar : ctx->h_stage + (pin_in ? 0 : (size_t)batch * rowlen);
     // Results: the kernels write logL straight into the page-locked block (its device address), 8 bytes per live
     // point over PCIe, which saves the D2H copy command of every block -- the last one is on the critical path.
@@ -916,6 +938,14 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
     const char* what = "";
     rc = MCALF_OK;
     double t_stage = 0, t_enq = 0, t_hwait = 0, t_first = 0, stage_bytes = 0;
+    const bool timeline = ctx->host_trace >= 2;
+    hipEvent_t tev[3 * kMaxChunks + 1] = {};
+    if (timeline) {
+        for (hipEvent_t& e : tev) (void)hipEventCreate(&e);
+        (void)hipEventRecord(tev[3 * kMaxChunks], ctx->stream);
+        g_block_timeline = BlockTimeline();
+        g_block_timeline.pinned = pin_in ? 1 : 0;
+    }
     for (int c = 0; c < nchunks && rc == MCALF_OK && he == hipSuccess; ++c) {
         const int64_t r0 = bounds[c], n = bounds[c + 1] - r0;
         if (n == 0) continue;
@@ -935,8 +965,13 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
             src = stage_in + (size_t)r0 * rowlen;
         }
         const double t1 = trace ? now_us() : 0.0;
-        he = hipMemcpyAsync(ctx->d_P + (size_t)r0 * rowlen, src, (size_t)n * rowlen * sizeof(double), hipMemcpyHostToDevice, st);
+        if (timeline) (void)hipEventRecord(tev[3 * c], copy_stream);
+        he = hipMemcpyAsync(ctx->d_P + (size_t)r0 * rowlen, src, (size_t)n * rowlen * sizeof(double), hipMemcpyHostToDevice, copy_stream);
         if (he != hipSuccess) { what = "H2D copy of a row block"; break; }
+        if (timeline) (void)hipEventRecord(tev[3 * c + 1], copy_stream);
+        he = hipEventRecord(ctx->ev_h2d[c], copy_stream);
+        if (he == hipSuccess) he = hipStreamWaitEvent(st, ctx->ev_h2d[c], 0);
+        if (he != hipSuccess) { what = "ordering a row block's kernels behind its H2D copy"; break; }
         rc = launch_range(ctx, mode, ctx->d_P, r0, n, c, targonly, fill, d_stage_out ? d_stage_out : ctx->d_out, nullptr, st,
                           false, nullptr, nchunks == 1);
         if (rc != MCALF_OK) break;
@@ -944,17 +979,27 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
             he = hipMemcpyAsync(stage_out + r0, ctx->d_out + r0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
             if (he != hipSuccess) { what = "D2H copy of a result block"; break; }
         }
+        if (timeline) { (void)hipEventRecord(tev[3 * c + 2], st); g_block_timeline.rows[c] = (long)n; g_block_timeline.host_enq[c] = now_us() - t_begin; g_block_timeline.n = c + 1; }
         if (trace) { const double t2 = now_us(); t_enq += t2 - t1; if (c == 0) t_first = t2 - t_begin; }
     }
     for (int h = 0; h < helpers; ++h) (void)ctx->stagers[h]->wait();      // (the job lives on this frame)
     const double t_w0 = trace ? now_us() : 0.0;
     const hipError_t s0 = hipStreamSynchronize(ctx->stream);
-    const hipError_t s1 = (nchunks > 1) ? hipStreamSynchronize(ctx->aux[0]) : hipSuccess;
+    hipError_t s1 = (nchunks > 1) ? hipStreamSynchronize(ctx->aux[0]) : hipSuccess;
+    { const hipError_t s2 = hipStreamSynchronize(copy_stream); if (s1 == hipSuccess) s1 = s2; }    // (a copy no kernel waited for, after a failure)
     if (rc != MCALF_OK) return rc;                                   // (message set by launch_range)
     if (he != hipSuccess) return set_err(ctx, MCALF_ERR_HIP, "%s failed: %s", what, hipGetErrorString(he));
     if (s0 != hipSuccess || s1 != hipSuccess)
         return set_err(ctx, MCALF_ERR_HIP, "stream synchronisation failed: %s", hipGetErrorString(s0 != hipSuccess ? s0 : s1));
     const double t_w1 = trace ? now_us() : 0.0;
+    if (timeline) {
+        for (int c = 0; c < g_block_timeline.n; ++c) {
+            (void)hipEventElapsedTime(&g_block_timeline.h2d0[c], tev[3 * kMaxChunks], tev[3 * c]);
+            (void)hipEventElapsedTime(&g_block_timeline.h2d1[c], tev[3 * kMaxChunks], tev[3 * c + 1]);
+            (void)hipEventElapsedTime(&g_block_timeline.done[c], tev[3 * kMaxChunks], tev[3 * c + 2]);
+        }
+        for (hipEvent_t e : tev) if (e) (void)hipEventDestroy(e);
+    }
     if (!pin_out) std::memcpy(out_scalar, stage_out, (size_t)batch * sizeof(double));
     if (trace) {
         HostTrace& t = g_host_trace;
@@ -1033,8 +1078,15 @@ static int run_host(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc;
-    if (out_scalar && !out_model && (size_t)batch * rowlen <= kSmallDoubles && (size_t)batch <= kSmallDoubles)
+    if (out_scalar && !out_model && (size_t)batch * rowlen <= kSmallDoubles && (size_t)batch <= kSmallDoubles) {
+        // (a batch that is small in bytes but reaches the streaming launch's item count -- MCALF_STREAM_MIN items per
+        // workgroup slot -- streams: one launch that sets its live points up itself, instead of set-up + fused kernel)
+        if ((mode == kModeLogL || mode == kModeChi2) && stream_qualifies(ctx, batch)) {
+            bool taken = false;
+            if ((rc = run_host_stream(ctx, mode, P, batch, rowlen, out_scalar, &taken)) != MCALF_OK || taken) return rc;
+        }
         return run_host_small(ctx, mode, P, batch, rowlen, targonly, fill, out_scalar, false, nullptr);
+    }
     if ((rc = grow(ctx, &ctx->d_P, &ctx->cap_P, (size_t)batch * rowlen))) return rc;
     if (out_scalar && (rc = grow(ctx, &ctx->d_out, &ctx->cap_out, (size_t)batch))) return rc;
     if (out_model && (rc = grow(ctx, &ctx->d_model, &ctx->cap_model, (size_t)batch * ctx->npix))) return rc;
@@ -1134,8 +1186,13 @@ extern "C" int mcalf_loglike_cube_batch(mcalf_ctx* ctx, const double* cube, int6
     int rc;
     // the paths of mcalf_loglike_batch, with the prior transform applied while the rows are decoded and the transformed
     // rows formed on the host under the launch: the zero-copy small call, ONE streaming launch for large batches
-    if (total <= kSmallDoubles && (size_t)batch <= kSmallDoubles)
+    if (total <= kSmallDoubles && (size_t)batch <= kSmallDoubles) {
+        if (stream_qualifies(ctx, batch)) {
+            bool taken = false;
+            if ((rc = run_host_stream(ctx, kModeLogL, cube, batch, ctx->ndim, logL, &taken, true, theta)) != MCALF_OK || taken) return rc;
+        }
         return run_host_small(ctx, kModeLogL, cube, batch, ctx->ndim, 0, 0, logL, true, theta);
+    }
     {
         bool taken = false;
         if ((rc = run_host_stream(ctx, kModeLogL, cube, batch, ctx->ndim, logL, &taken, true, theta)) != MCALF_OK || taken) return rc;

@@ -34,10 +34,11 @@ EnvKnobs read_environment() {
         }
     }
     if (env_int("MCALF_HOST_FIRST_KB", &v) && v > 0) k.host_first_kb = std::min(v, 1 << 20);
-    if (env_int("MCALF_HOST_TRACE", &v)) k.host_trace = v != 0;
+    if (env_int("MCALF_HOST_TRACE", &v)) k.host_trace = std::min(std::max(v, 0), 2);
     if (env_int("MCALF_STAGE_THREADS", &v)) k.stage_threads = std::min(std::max(v, 0), 8);
     if (env_int("MCALF_STREAM", &v)) k.stream = std::min(std::max(v, 0), 2);
     if (env_int("MCALF_STREAM_WGS", &v)) k.stream_wgs = std::max(v, 1);
+    if (env_int("MCALF_STREAM_MIN", &v)) k.stream_min = std::min(std::max(v, 1), 64);
     if (env_int("MCALF_STREAM_POLL", &v)) k.stream_poll = v != 0;
     if (env_int("MCALF_STREAM_EAGER", &v)) k.stream_eager = std::max(v, 0);
     if (env_int("MCALF_STREAM_CHUNK", &v)) k.stream_chunk = std::min(std::max(v & ~7, 8), 512);
@@ -71,6 +72,7 @@ void apply_environment(mcalf_ctx* ctx) {
     if (k.host_trace >= 0) ctx->host_trace = k.host_trace;
     if (k.stage_threads >= 0) ctx->stage_threads = k.stage_threads;
     if (k.stream >= 0) ctx->stream_on = k.stream;
+    if (k.stream_min >= 0) ctx->stream_min = k.stream_min;
     if (k.stream_poll >= 0) ctx->stream_poll = k.stream_poll;
     if (k.stream_eager >= 0) ctx->stream_eager = k.stream_eager;
     if (k.stream_chunk >= 0) ctx->stream_chunk = k.stream_chunk;
@@ -97,8 +99,8 @@ extern "C" int mcalf_get_config(const mcalf_ctx* ctx, char* buf, int64_t n) {
     if (ctx->host_plan_n == 0) s += "auto";
     for (int i = 0; i < ctx->host_plan_n; ++i) add(i ? ",%d" : "%d", ctx->host_plan[i]);
     add(" host_first_kb=%d host_trace=%d stage_threads=%d ", ctx->host_first_kb, ctx->host_trace, ctx->stage_threads);
-    add("stream=%d stream_wgs=%d stream_poll=%d stream_eager=%d stream_chunk=%d stream_device=%d stream_trace=%d stream_timeout_s=%g ",
-        ctx->stream_on, ctx->stream_wgs, ctx->stream_poll, ctx->stream_eager, ctx->stream_chunk, ctx->stream_device, ctx->stream_trace,
+    add("stream=%d stream_min=%d stream_wgs=%d stream_poll=%d stream_eager=%d stream_chunk=%d stream_device=%d stream_trace=%d stream_timeout_s=%g ",
+        ctx->stream_on, ctx->stream_min, ctx->stream_wgs, ctx->stream_poll, ctx->stream_eager, ctx->stream_chunk, ctx->stream_device, ctx->stream_trace,
         ctx->stream_timeout_s);
     add("xcd_mask=0x%x cu_mask_words=%d wide_lsf=%d", ctx->xcd_mask, (int)ctx->cu_mask.size(), ctx->wide);
     s += " [env:";
@@ -106,7 +108,7 @@ extern "C" int mcalf_get_config(const mcalf_ctx* ctx, char* buf, int64_t n) {
     named(k.lines_per_sync >= 0, "MCALF_LINES_PER_SYNC"); named(k.persist >= 0, "MCALF_PERSIST"); named(k.order >= 0, "MCALF_ORDER");
     named(k.inline_max >= 0, "MCALF_INLINE_MAX"); named(k.resident_us >= 0, "MCALF_RESIDENT_US"); named(k.setup_block >= 0, "MCALF_SETUP_BLOCK");
     named(k.host_plan_n > 0, "MCALF_HOST_PLAN"); named(k.host_first_kb >= 0, "MCALF_HOST_FIRST_KB"); named(k.host_trace >= 0, "MCALF_HOST_TRACE");
-    named(k.stage_threads >= 0, "MCALF_STAGE_THREADS"); named(k.stream >= 0, "MCALF_STREAM"); named(k.stream_wgs >= 0, "MCALF_STREAM_WGS");
+    named(k.stage_threads >= 0, "MCALF_STAGE_THREADS"); named(k.stream >= 0, "MCALF_STREAM"); named(k.stream_min >= 0, "MCALF_STREAM_MIN"); named(k.stream_wgs >= 0, "MCALF_STREAM_WGS");
     named(k.stream_poll >= 0, "MCALF_STREAM_POLL"); named(k.stream_eager >= 0, "MCALF_STREAM_EAGER"); named(k.stream_chunk >= 0, "MCALF_STREAM_CHUNK");
     named(k.stream_device >= 0, "MCALF_STREAM_DEVICE"); named(k.stream_trace >= 0, "MCALF_STREAM_TRACE");
     named(k.stream_timeout_s > 0.0, "MCALF_STREAM_TIMEOUT"); named(k.chunks >= 0, "MCALF_CHUNKS"); named(!k.rccl_lib.empty(), "MCALF_RCCL_LIB");

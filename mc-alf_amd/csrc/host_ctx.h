@@ -109,6 +109,7 @@ struct EnvKnobs {
     int stage_threads = -1;                 // MCALF_STAGE_THREADS    helper threads of the staging copy (0: the calling thread alone)
     int stream = -1;                        // MCALF_STREAM           0 / 1 / 2
     int stream_wgs = -1;                    // MCALF_STREAM_WGS
+    int stream_min = -1;                    // MCALF_STREAM_MIN       1 .. 64 work items per workgroup slot
     int stream_poll = -1;                   // MCALF_STREAM_POLL      0 / 1
     int stream_eager = -1;                  // MCALF_STREAM_EAGER
     int stream_chunk = -1;                  // MCALF_STREAM_CHUNK     8 .. 512, a multiple of 8
@@ -194,6 +195,7 @@ struct mcalf_ctx {
     int ordered = 1;                    // MCALF_ORDER=0: hand the live points out in row order
     hipStream_t aux[kMaxChunks - 1] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxChunks - 1] = {};
+    hipEvent_t ev_h2d[kMaxChunks] = {};     // row-block pipeline: block k's rows are in HBM (recorded on the copy stream, aux[1])
     // multi-GPU: the communicator of mcalf_comm_init (one process per GPU, RCCL over xGMI)
     ncclComm_t comm = nullptr;
     int comm_ranks = 0, comm_rank = -1;
@@ -232,6 +234,7 @@ struct mcalf_ctx {
     int stream_on = 1;                      // MCALF_STREAM: 0 = the row-block pipeline of round 2 instead; 1 = automatic (spectra that
                                             // fit one tile: measured, config E's five tiles per live point run 1.3 % faster through
                                             // the pipeline); 2 = always
+    int stream_min = 4;                     // MCALF_STREAM_MIN: work items per workgroup slot from which a host-pointer batch streams
     int stream_wgs = 16;                    // MCALF_STREAM_WGS: workgroups dedicated to the set-up while rows are outstanding
     int stream_eager = 0;                   // MCALF_STREAM_EAGER: blocks of 8 rows per XCD any workgroup may set up (0: what the first items need)
     int stream_chunk = 32;                  // MCALF_STREAM_CHUNK: rows such a workgroup claims (and copies to HBM) at a time
@@ -255,7 +258,7 @@ struct mcalf_ctx {
     int multi_last_active = 0;              // sub-contexts the last call was cut over
 };
 inline bool is_multi(const mcalf_ctx* ctx) { return !ctx->subs.empty(); }
-constexpr int kCtlWords = 64, kCtlArrived = 16;
+constexpr int kCtlWords = 64, kCtlArrived = 16, kCtlFinalized = 4;   // ([4]: stamp of the last streaming launch whose FINALIZE kernel has finished)
 
 // ---- host_abi.cpp ---------------------------------------------------------------------------------------------------
 int set_err(mcalf_ctx* ctx, int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
@@ -295,7 +298,7 @@ int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targon
            double* d_model, hipStream_t stream, bool from_cube = false, double* d_theta = nullptr);
 // Everything of a launch that can fail WITHOUT anything having been enqueued (range check, workspace growth).
 int launch_preflight(mcalf_ctx* ctx, int mode, int64_t batch);
-int launch_finalize(mcalf_ctx* ctx, const KArgs& a, int64_t nrows, int mode, hipStream_t stream, int nparts = 0);
+int launch_finalize(mcalf_ctx* ctx, const KArgs& a, int64_t nrows, int mode, hipStream_t stream, int nparts = 0, bool signal = false);
 int ensure_small(mcalf_ctx* ctx);                      // the page-locked block of small calls
 bool is_pinned_host(const void* p);
 // A stream of the context: created with the context's CU mask when it has one (mcalf_set_cu_mask).

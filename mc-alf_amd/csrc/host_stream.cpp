@@ -87,7 +87,7 @@ int stream_launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, dou
     a.stream_wgs = wgs / kXcds;                           // (per XCD)
     // The words this launch will write are cleared first: the completion word of the previous launch must not be taken
     // for this one's, whatever the generation counts are.
-    ctx->h_ctl[1] = 0u; ctx->h_ctl[2] = 0u; ctx->h_ctl[3] = 0u;
+    ctx->h_ctl[1] = 0u; ctx->h_ctl[2] = 0u; ctx->h_ctl[3] = 0u; ctx->h_ctl[kCtlFinalized] = 0u;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     a.eager_rows = (int)std::min<int64_t>((batch + 7) / 8, eager_rows);      // (local blocks of eight rows per XCD)
     a.spin_ticks = (long long)(ctx->stream_timeout_s * 1e8);
@@ -108,7 +108,8 @@ int stream_launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, dou
         HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->ev_used + 1], stream));
         ctx->ev_used += 2;
     }
-    if ((mode == kModeLogL || mode == kModeChi2) && ctx->ntiles > 1) return launch_finalize(ctx, a, batch, mode, stream);
+    // (tiled spectra: the finalize kernel writes the results; when they go to page-locked host memory it also tells the host)
+    if ((mode == kModeLogL || mode == kModeChi2) && ctx->ntiles > 1) return launch_finalize(ctx, a, batch, mode, stream, 0, host_rows);
     return MCALF_OK;
 }
 
@@ -116,7 +117,7 @@ bool stream_qualifies(const mcalf_ctx* ctx, int64_t batch) {
     const int64_t slots = 2LL * ctx->num_cu, nitems = batch * ctx->ntiles;
     // (never a wide-LSF context: its convolution runs in the wide kernels behind a convolution-free fused launch -- the
     // streaming workspaces and the tile's LDS carry no halo for it)
-    return !ctx->wide && ctx->persist && nitems >= 4 * slots && nitems <= 0x7fff0000LL && batch <= 0x7fff0000LL;
+    return !ctx->wide && ctx->persist && nitems >= ctx->stream_min * slots && nitems <= 0x7fff0000LL && batch <= 0x7fff0000LL;
 }
 
 // Which XCDs do workgroups launched on the context's stream run on?  The streaming launch deals its rows to the XCDs
@@ -272,10 +273,11 @@ int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
     // Completion: the word the last workgroup writes once every result has been acknowledged (a stream wait costs an
     // interrupt and a thread wake-up); the stream is asked now and then so that a faulted launch cannot keep us here.
     bool polled = false;
-    if (he == hipSuccess && ctx->stream_poll && !tiled) {
+    if (he == hipSuccess && ctx->stream_poll) {
         const unsigned int want = ctx->stream_gen;
+        const volatile unsigned int* word = ctx->h_ctl + (tiled ? kCtlFinalized : 1);     // (tiled: the finalize kernel's word)
         for (unsigned long spins = 0;; ++spins) {
-            if (__atomic_load_n(const_cast<unsigned int*>(ctx->h_ctl + 1), __ATOMIC_ACQUIRE) == want) { polled = true; break; }
+            if (__atomic_load_n(const_cast<unsigned int*>(word), __ATOMIC_ACQUIRE) == want) { polled = true; break; }
             if ((spins & 0xFFFFul) == 0xFFFFul && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;
             __builtin_ia32_pause();
         }

@@ -131,6 +131,7 @@ struct StreamCtl {                      // per XCD x: its own queues over ITS li
     unsigned int sq_rest[kXcds];        // local blocks claimed of the rest: the XCD's dedicated workgroups
     unsigned int queue[kXcds];          // local tickets handed out by the XCD's item queue
     unsigned int exited;                // workgroups that have left the kernel
+    unsigned int fin_exited;            // workgroups of the finalize kernel behind it (tiled spectra) that have finished
 };
 // status[0] of a streaming launch (0 = nobody gave up)
 constexpr unsigned kStreamHostLate = 1u;     // a wait for the host's row count ran out
@@ -199,7 +200,7 @@ MCALF_INTERNAL int fused_kernel_count();                       // every instanti
 MCALF_INTERNAL const void* fused_kernel_at(int i);
 MCALF_INTERNAL const void* resident_kernel_ptr(bool jax, bool selfhalo);
 MCALF_INTERNAL const void* sample_kernel_ptr(bool jax);        // (const KArgs a, long batch)
-MCALF_INTERNAL const void* finalize_kernel_ptr();              // (const double* partial, double* out, long batch, int ntiles, int mode, int asymm, double veto4, double veto5)
+MCALF_INTERNAL const void* finalize_kernel_ptr();              // (const double* partial, double* out, long batch, int ntiles, int mode, int asymm, double veto4, double veto5, unsigned* fin_count, unsigned* done_word, unsigned gen)
 MCALF_INTERNAL const void* hjert_kernel_ptr();                 // (const double* x, const double* y, long n, double* out, const double* tabs, int node_form)
 MCALF_INTERNAL const void* scale_cube_kernel_ptr();            // (const double* lo, const double* hi, const double* cube, long total, int ndim, int slot, int int_ncomp, double* theta)
 MCALF_INTERNAL const void* xcd_probe_kernel_ptr();             // (unsigned int* mask): ORs 1 << XCC_ID of every workgroup into *mask

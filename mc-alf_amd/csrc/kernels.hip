@@ -1314,16 +1314,32 @@ __global__ __launch_bounds__(kBlock, 2) void mcalf_resident_kernel(const KArgs a
     }
 }
 
+// done_word != nullptr (the streaming launch of a TILED spectrum): `out` is page-locked host memory the host reads as soon as
+// *done_word == gen -- results go out as system-scope stores, and the last workgroup to finish (fin_count, re-armed by
+// it) writes the word behind them, as stream_exit() does for single-tile spectra.
 __global__ void mcalf_finalize_kernel(const double* partial, double* out, long batch, int ntiles, int mode,
-                                      int asymm, double veto4, double veto5) {
+                                      int asymm, double veto4, double veto5, unsigned int* fin_count, unsigned int* done_word,
+                                      unsigned int gen) {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= batch) return;
-    double sum = 0.0, cnt = 0.0, c4 = 0.0, c5 = 0.0;
-    for (int t = 0; t < ntiles; ++t) {
-        const double* pr = partial + (s * ntiles + t) * 4;
-        sum += pr[0]; cnt += pr[1]; c4 += pr[2]; c5 += pr[3];
+    if (s < batch) {
+        double sum = 0.0, cnt = 0.0, c4 = 0.0, c5 = 0.0;
+        for (int t = 0; t < ntiles; ++t) {
+            const double* pr = partial + (s * ntiles + t) * 4;
+            sum += pr[0]; cnt += pr[1]; c4 += pr[2]; c5 += pr[3];
+        }
+        const double val = finalize_value(mode, sum, cnt, asymm != 0, c4, c5, veto4, veto5);
+        if (done_word) __hip_atomic_store(out + s, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else out[s] = val;
     }
-    out[s] = finalize_value(mode, sum, cnt, asymm != 0, c4, c5, veto4, veto5);
+    if (done_word) {                                         // (grid-uniform)
+        stream_stores_done();
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(fin_count, 1u) == gridDim.x - 1) {
+            __hip_atomic_store(fin_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stream_stores_done();
+            __hip_atomic_store(done_word, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 __global__ void mcalf_hjert_kernel(const double* x, const double* y, long n, double* out, const double* tabs,

@@ -86,8 +86,8 @@ PY
       run oldplan_$round MCALF_HOST_PLAN=1,1,2,4
       run stream2_$round MCALF_STREAM=2
       run helper1_$round MCALF_STAGE_THREADS=1
-      run helper2_$round MCALF_STAGE_THREADS=2
-      run inline1024_$round MCALF_INLINE_MAX=1024
+      run bstream_$round MCALF_STREAM_MIN=2 MCALF_STREAM_EAGER=16
+      run bstream_wgs_$round MCALF_STREAM_MIN=2 MCALF_STREAM_WGS=64 MCALF_STREAM_CHUNK=8
     done
     cat "$out/hostgap.txt" ;;
   *) echo "unknown recipe $recipe"; exit 2 ;;
