@@ -314,6 +314,8 @@ typedef struct {
     int32_t pinned_in;      /* host-pointer entries: the parameter rows were page-locked caller memory        */
     int32_t pinned_out;     /* host-pointer entries: the result array was page-locked caller memory           */
     int32_t inline_setup;   /* 1: small launch -- ONE kernel, the per-sample set-up ran inside the fused kernel;
+                               2: MCALF_PATH_HOST_ZEROCOPY call that launched BEFORE it copied its rows (>= 32 KB of them): the
+                                  set-up kernel waited for the host's row count, launch latency and copy overlapped;
                                3: no launch at all -- the context's resident evaluator answered (mcalf_set_resident) */
     int32_t ordered;        /* 1: the persistent grid handed the live points out sorted by component count      */
     int32_t stream_setup_wgs; /* MCALF_PATH_HOST_STREAM: workgroups of the grid dedicated to the set-up while rows were outstanding */
@@ -339,15 +341,18 @@ int mcalf_last_launch(const mcalf_ctx* ctx, mcalf_launch_info_t* info);
 /* The same for device entry k of a multi-device context (mcalf_last_launch itself reports entry 0 and devices_used). */
 int mcalf_last_launch_sub(const mcalf_ctx* ctx, int32_t k, mcalf_launch_info_t* info);
 
-/* Restrict the context's own streams (the host-pointer entries; *_device entries run on the CALLER's stream) to the
+/* Restrict EVERY stream the context owns -- the launch stream of the host-pointer entries and its auxiliaries, the resident
+ * evaluator's stream (its kernel is stopped first; the next one-theta call starts another), the exchange stream of the
+ * library's gather (pending exchanges are waited for) -- (*_device entries run on the CALLER's stream) to the
  * compute units of `mask` -- bit i % 32 of word i / 32 = CU i in the runtime's numbering (hipExtStreamCreateWithCUMask; on a
  * multi-XCD device consecutive bits go round the XCDs: bit i = CU i / 8 of XCD i % 8) -- as an embedding application does to
  * share one GPU between ranks.  nwords = 0 removes the mask.  The context waits for its streams, re-creates them and probes
  * again which XCDs they reach: on anything but all eight XCDs of an unpartitioned MI355X large host-pointer batches take the
  * row-block pipeline instead of the streaming launch (mcalf_launch_info_t.xcd_mask / .stream_fallback say so).  Measured on
  * ROCm 7.2 / MI355X (tools/explore/cu_mask_probe.py): an XCD whose share of the mask is EMPTY runs unrestricted, so a mask
- * slows a stream down but cannot take an XCD away from it -- what does is a partition mode (DPX / QPX / CPX).  Results
- * never depend on the mask. */
+ * slows a stream down but cannot take an XCD away from it -- what does is a partition mode (DPX / QPX / CPX).  A masked
+ * stream is a BLOCKING stream in HIP's sense (hipExtStreamCreateWithCUMask has no non-blocking form): it synchronises with
+ * work on the legacy default stream, which an unmasked context's streams do not.  Results never depend on the mask. */
 int mcalf_set_cu_mask(mcalf_ctx* ctx, const uint32_t* mask, int32_t nwords);
 
 /* How a streaming launch deals the rows of a batch to `nxcd` XCDs (blocks of eight rows, block k -> XCD k % nxcd): for

@@ -26,7 +26,7 @@ int resident_call(mcalf_ctx* ctx, const double* row, int rowlen, double* out) {
         HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_box, sizeof(ResidentBox), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset((void*)ctx->h_box, 0, sizeof(ResidentBox));
         HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->d_box, (void*)ctx->h_box, 0));
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->res_stream, hipStreamNonBlocking));
+        { const int rcs = create_stream(ctx, &ctx->res_stream); if (rcs) return rcs; }      // (with the context's CU mask, when it has one)
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_res_shared, sizeof(ResidentShared)));
         const void* k = resident_kernel_ptr(ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX, ctx->selfhalo != 0);
         HIP_TRY(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsBudget + 1024)));

@@ -155,7 +155,7 @@ extern "C" int mcalf_comm_join(mcalf_ctx* ctx, void* stream) {
 }
 
 static int comm_ensure_streams(mcalf_ctx* ctx) {
-    if (!ctx->comm_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    if (!ctx->comm_stream) { const int rcs = create_stream(ctx, &ctx->comm_stream); if (rcs) return rcs; }   // (with the context's CU mask, when it has one)
     if (!ctx->ev_kernels) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_kernels, hipEventDisableTiming));
     for (hipEvent_t& e : ctx->ev_comm)
         if (!e) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));

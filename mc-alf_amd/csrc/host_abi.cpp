@@ -392,6 +392,12 @@ extern "C" int mcalf_set_cu_mask(mcalf_ctx* ctx, const uint32_t* mask, int32_t n
         return MCALF_OK;
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // EVERY stream the context owns is replaced: the launch stream and its auxiliaries, the resident evaluator's (its
+    // kernel is told to leave first: the next one-theta call starts another one on the new stream) and the exchange
+    // stream of the library's gather (pending exchanges are waited for; it is re-created by the next gather).
+    resident_stop(ctx);
+    if (ctx->res_stream) { HIP_TRY(ctx, hipStreamSynchronize(ctx->res_stream)); HIP_TRY(ctx, hipStreamDestroy(ctx->res_stream)); ctx->res_stream = nullptr; }
+    if (ctx->comm_stream) { HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream)); HIP_TRY(ctx, hipStreamDestroy(ctx->comm_stream)); ctx->comm_stream = nullptr; }
     // the context's own streams are idle between its (synchronous) host-pointer calls; wait anyway, then replace them
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (hipStream_t& st : ctx->aux)
@@ -524,7 +530,7 @@ int launch_finalize(mcalf_ctx* ctx, const KArgs& a, int64_t nrows, int mode, hip
 
 static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0, int64_t nrows, int chunk,
                         int targonly, int onecomp_fill, double* d_out, double* d_model, hipStream_t stream,
-                        bool from_cube, double* d_theta, bool timed_ok, int wide_stage = kWideNone) {
+                        bool from_cube, double* d_theta, bool timed_ok, int wide_stage = kWideNone, bool gated = false) {
     const bool reduces = (mode == kModeLogL || mode == kModeChi2);
     KArgs a = make_kargs(ctx, mode, dP, row0, nrows, chunk, targonly, onecomp_fill, d_out, d_model, from_cube, d_theta, wide_stage);
     // Persistent grid = the workgroup slots of the chip (2 per CU: LDS and the 4 waves per SIMD the kernel's
@@ -547,6 +553,10 @@ static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0
     // gap behind it are a fifth of such a call's latency.  Same set-up code, same bits.
     const bool inl = !a.persist && a.nitems <= ctx->inline_max_items;
     ctx->last.inline_setup = inl ? 1 : 0;
+    if (gated) {                                          // (run_host_small checked that this launch has a set-up kernel)
+        if (inl) return set_err(ctx, MCALF_ERR_INVALID, "internal: a gated launch needs the set-up kernel");
+        a.arrived = ctx->d_ctl + kCtlArrived; a.status = ctx->d_ctl; a.spin_ticks = (long long)(ctx->stream_timeout_s * 1e8);
+    }
     if (!inl) {
         const int per_wg = ctx->setup_block / 64;             // live points per set-up workgroup (one wave each)
         const dim3 sgrid((unsigned)((nrows + per_wg - 1) / per_wg) + (a.order ? 1u : 0u)), sblock((unsigned)ctx->setup_block);
@@ -676,7 +686,7 @@ static int launch_wide(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch
 }
 
 int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill,
-           double* d_out, double* d_model, hipStream_t stream, bool from_cube, double* d_theta) {
+           double* d_out, double* d_model, hipStream_t stream, bool from_cube, double* d_theta, bool gated) {
     if (batch == 0) return MCALF_OK;
     int rc;
     if (ctx->wide) return launch_wide(ctx, mode, dP, batch, targonly, onecomp_fill, d_out, d_model, stream, from_cube, d_theta);
@@ -698,7 +708,8 @@ int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targon
     ctx->last.row_blocks = nchunks;
     if (nchunks == 1)
         return launch_range(ctx, mode, dP, 0, batch, 0, targonly, onecomp_fill, d_out, d_model, stream, from_cube,
-                            d_theta, true);
+                            d_theta, true, kWideNone, gated);
+    if (gated) return set_err(ctx, MCALF_ERR_INVALID, "internal: a gated launch is ONE row block");
     if ((rc = ensure_aux(ctx, nchunks - 1))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, stream));
     for (int c = 0; c < nchunks; ++c) {
@@ -792,11 +803,12 @@ bool is_pinned_host(const void* p) {
 // is destroyed (mean microseconds per call): staging copies by the calling thread (and the rate they ran at), copies its
 // helper took over, enqueueing (H2D commands + launches), the wait for the streams, the copy of the results.
 namespace {
-struct HostTrace { double stage_us = 0, stage_bytes = 0, helper_bytes = 0, helper_wait_us = 0, enqueue_us = 0, wait_us = 0, out_us = 0, first_enqueued_us = 0; long calls = 0, blocks = 0; };
+struct HostTrace { double stage_us = 0, stage_bytes = 0, helper_bytes = 0, helper_wait_us = 0, enqueue_us = 0, wait_us = 0, out_us = 0, first_enqueued_us = 0;
+                   double call_copy_us = 0, call_order_us = 0, call_launch_us = 0, call_copy_max = 0; long calls = 0, blocks = 0; };
 HostTrace g_host_trace;
 // MCALF_HOST_TRACE=2: additionally the GPU-side timeline of the LAST pipelined call -- per row block the times (us after the
 // call began) at which its H2D copy started and ended and its kernels ended on the device, and when the host enqueued it
-struct BlockTimeline { int n = 0; long rows[kMaxChunks]; float h2d0[kMaxChunks], h2d1[kMaxChunks], done[kMaxChunks]; double host_enq[kMaxChunks]; int pinned = 0; };
+struct BlockTimeline { int n = 0; long rows[kMaxChunks]; float h2d0[kMaxChunks], h2d1[kMaxChunks], done[kMaxChunks]; double host_enq[kMaxChunks], call_h2d[kMaxChunks], call_order[kMaxChunks], call_launch[kMaxChunks]; int pinned = 0; double sync_us = 0; };
 BlockTimeline g_block_timeline;
 
 // The staging copy of one call, shared between the calling thread (blocks from the front, in the order the GPU wants
@@ -827,14 +839,18 @@ void host_trace_report(const mcalf_ctx* ctx) {
     const HostTrace& t = g_host_trace;
     const double n = (double)t.calls;
     std::fprintf(stderr, "mcalf host trace (row-block pipeline, %ld calls, %.1f blocks per call; us per call): staging copy by the caller %.1f "
-                 "(%.2f GB/s), by helpers %.0f KB (waited %.1f), first block enqueued at %.1f, enqueue %.1f, wait for the streams %.1f, "
+                 "(%.2f GB/s), by helpers %.0f KB (waited %.1f), first block enqueued at %.1f, enqueue %.1f (of it: hipMemcpyAsync calls %.1f [longest single "
+                 "call %.1f], event record + wait %.1f, launches %.1f), wait for the streams %.1f, "
                  "results out %.1f\n", t.calls, (double)t.blocks / n, t.stage_us / n, t.stage_us > 0 ? t.stage_bytes / t.stage_us * 1e-3 : 0.0,
-                 t.helper_bytes / n / 1024.0, t.helper_wait_us / n, t.first_enqueued_us / n, t.enqueue_us / n, t.wait_us / n, t.out_us / n);
+                 t.helper_bytes / n / 1024.0, t.helper_wait_us / n, t.first_enqueued_us / n, t.enqueue_us / n, t.call_copy_us / n, t.call_copy_max,
+                 t.call_order_us / n, t.call_launch_us / n, t.wait_us / n, t.out_us / n);
     g_host_trace = HostTrace();
     const BlockTimeline& b = g_block_timeline;
     for (int c = 0; c < b.n; ++c)
-        std::fprintf(stderr, "mcalf host trace, last call (%s rows), block %d: %ld rows, enqueued by the host at %.1f us; on the device: H2D %.1f .. %.1f, "
-                     "kernels done %.1f\n", b.pinned ? "page-locked" : "pageable", c, b.rows[c], b.host_enq[c], b.h2d0[c] * 1e3, b.h2d1[c] * 1e3, b.done[c] * 1e3);
+        std::fprintf(stderr, "mcalf host trace, last call (%s rows), block %d: %ld rows, enqueued by the host at %.1f us (calls: copy %.1f, ordering %.1f, launches %.1f); "
+                     "on the device: H2D %.1f .. %.1f, kernels done %.1f\n", b.pinned ? "page-locked" : "pageable", c, b.rows[c], b.host_enq[c], b.call_h2d[c], b.call_order[c],
+                     b.call_launch[c], b.h2d0[c] * 1e3, b.h2d1[c] * 1e3, b.done[c] * 1e3);
+    if (b.n) std::fprintf(stderr, "mcalf host trace, last call: the stream waits returned %.1f us after the call began\n", b.sync_us);
     g_block_timeline = BlockTimeline();
 }
 
@@ -966,18 +982,27 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
         }
         const double t1 = trace ? now_us() : 0.0;
         if (timeline) (void)hipEventRecord(tev[3 * c], copy_stream);
+        const double tc0 = trace ? now_us() : 0.0;
         he = hipMemcpyAsync(ctx->d_P + (size_t)r0 * rowlen, src, (size_t)n * rowlen * sizeof(double), hipMemcpyHostToDevice, copy_stream);
         if (he != hipSuccess) { what = "H2D copy of a row block"; break; }
+        const double tc1 = trace ? now_us() : 0.0;
         if (timeline) (void)hipEventRecord(tev[3 * c + 1], copy_stream);
         he = hipEventRecord(ctx->ev_h2d[c], copy_stream);
         if (he == hipSuccess) he = hipStreamWaitEvent(st, ctx->ev_h2d[c], 0);
         if (he != hipSuccess) { what = "ordering a row block's kernels behind its H2D copy"; break; }
+        const double tc2 = trace ? now_us() : 0.0;
         rc = launch_range(ctx, mode, ctx->d_P, r0, n, c, targonly, fill, d_stage_out ? d_stage_out : ctx->d_out, nullptr, st,
                           false, nullptr, nchunks == 1);
         if (rc != MCALF_OK) break;
         if (!d_stage_out) {
             he = hipMemcpyAsync(stage_out + r0, ctx->d_out + r0, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
             if (he != hipSuccess) { what = "D2H copy of a result block"; break; }
+        }
+        if (trace) {
+            const double tc3 = now_us();
+            g_host_trace.call_copy_us += tc1 - tc0; g_host_trace.call_order_us += tc2 - tc1; g_host_trace.call_launch_us += tc3 - tc2;
+            g_host_trace.call_copy_max = std::max(g_host_trace.call_copy_max, tc1 - tc0);
+            if (timeline) { g_block_timeline.call_h2d[c] = tc1 - tc0; g_block_timeline.call_order[c] = tc2 - tc1; g_block_timeline.call_launch[c] = tc3 - tc2; }
         }
         if (timeline) { (void)hipEventRecord(tev[3 * c + 2], st); g_block_timeline.rows[c] = (long)n; g_block_timeline.host_enq[c] = now_us() - t_begin; g_block_timeline.n = c + 1; }
         if (trace) { const double t2 = now_us(); t_enq += t2 - t1; if (c == 0) t_first = t2 - t_begin; }
@@ -993,6 +1018,7 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
         return set_err(ctx, MCALF_ERR_HIP, "stream synchronisation failed: %s", hipGetErrorString(s0 != hipSuccess ? s0 : s1));
     const double t_w1 = trace ? now_us() : 0.0;
     if (timeline) {
+        g_block_timeline.sync_us = t_w1 - t_begin;
         for (int c = 0; c < g_block_timeline.n; ++c) {
             (void)hipEventElapsedTime(&g_block_timeline.h2d0[c], tev[3 * kMaxChunks], tev[3 * c]);
             (void)hipEventElapsedTime(&g_block_timeline.h2d1[c], tev[3 * kMaxChunks], tev[3 * c + 1]);
@@ -1023,12 +1049,26 @@ int ensure_small(mcalf_ctx* ctx) {
 // Small scalar-output calls (up to kSmallDoubles parameters: single-theta calls, config B's batch), zero-copy: a
 // single-theta call is dominated by the latency of its two copy commands.  from_cube / theta_out: as in run_host_stream.
 static int run_host_small(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
-                          double* out_scalar, bool from_cube, double* theta_out) {
+                          double* out_scalar, bool from_cube, double* theta_out, bool gate_ok = true) {
     int rc;
     if (resident_serves(ctx, mode, batch, rowlen, from_cube)) return resident_call(ctx, P, rowlen, out_scalar);
     if ((rc = ensure_small(ctx))) return rc;
-    std::memcpy(ctx->h_small, P, (size_t)batch * rowlen * sizeof(double));
-    ctx->last.path = MCALF_PATH_HOST_ZEROCOPY; ctx->last.pinned_in = ctx->last.pinned_out = 0;
+    // Launch first, copy afterwards (a call of at least 32 KB of rows whose launch has a set-up kernel: config B's 1024 rows):
+    // the set-up kernel's workgroups wait for the host's row count, so the launch latency (~5 us) runs under the copy (~4 us
+    // per 200 KB) instead of behind it.  Smaller calls -- the one-theta callables -- copy first: there is nothing to overlap.
+    const int64_t nitems = batch * ctx->ntiles;
+    const bool has_setup = (ctx->persist && nitems >= 4LL * 2 * ctx->num_cu) || nitems > ctx->inline_max_items;
+    const bool gated = gate_ok && ctx->small_gate && has_setup && !ctx->wide && !ctx->profiling && pick_chunks(ctx, batch) == 1 &&
+                       (size_t)batch * rowlen * sizeof(double) >= 32768 && !ctx->stream_device;
+    if (gated) {
+        if ((rc = ensure_ctl(ctx))) return rc;
+        ctx->h_ctl[0] = 0u;
+        ctx->h_ctl[kCtlArrived] = 0u;
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    } else {
+        std::memcpy(ctx->h_small, P, (size_t)batch * rowlen * sizeof(double));
+    }
+    ctx->last.path = MCALF_PATH_HOST_ZEROCOPY; ctx->last.pinned_in = ctx->last.pinned_out = 0; ctx->last.stream_fallback = 0;
     // Completion is read off the results: their slots are filled with a NaN no kernel produces, and the call is over
     // when none is left -- a stream wait costs an interrupt and a thread wake-up on top of the kernel, a fifth of a
     // one-theta call.  (The stream is asked now and then, so that a failed launch cannot keep the call here.)
@@ -1036,8 +1076,17 @@ static int run_host_small(mcalf_ctx* ctx, int mode, const double* P, int64_t bat
     const bool poll = ctx->stream_poll != 0;
     if (poll)
         for (int64_t i = 0; i < batch; ++i) __atomic_store_n(res + i, kResultPending, __ATOMIC_RELEASE);
-    rc = launch(ctx, mode, ctx->d_small, batch, targonly, fill, ctx->d_small + kSmallDoubles, nullptr, ctx->stream, from_cube);
+    rc = launch(ctx, mode, ctx->d_small, batch, targonly, fill, ctx->d_small + kSmallDoubles, nullptr, ctx->stream, from_cube, nullptr, gated);
     if (rc) return rc;
+    if (gated) {                                          // (nothing between the launch and the last publication can fail)
+        ctx->last.inline_setup = 2;
+        constexpr int64_t kRowsPerStep = 128;
+        for (int64_t r0 = 0; r0 < batch; r0 += kRowsPerStep) {
+            const int64_t n = std::min(kRowsPerStep, batch - r0);
+            std::memcpy(ctx->h_small + (size_t)r0 * rowlen, P + (size_t)r0 * rowlen, (size_t)n * rowlen * sizeof(double));
+            __atomic_store_n(const_cast<unsigned int*>(ctx->h_ctl + kCtlArrived), (unsigned int)(r0 + n), __ATOMIC_RELEASE);
+        }
+    }
     if (theta_out) host_scale_cube(ctx, P, batch, theta_out);       // (under the launch)
     bool done = false;
     if (poll) {
@@ -1051,6 +1100,11 @@ static int run_host_small(mcalf_ctx* ctx, int mode, const double* P, int64_t bat
     }
     if (!done) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->last.stream_polled = done ? 1 : 0;
+    if (gated && ctx->h_ctl[0] != 0u) {                   // a wait for the rows ran out inside the set-up kernel: the plain way
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->last.stream_fallback = MCALF_STREAM_FALLBACK_TIMEOUT;
+        return run_host_small(ctx, mode, P, batch, rowlen, targonly, fill, out_scalar, from_cube, theta_out, false);
+    }
     std::memcpy(out_scalar, ctx->h_small + kSmallDoubles, (size_t)batch * sizeof(double));
     return MCALF_OK;
 }

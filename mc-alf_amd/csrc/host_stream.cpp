@@ -50,6 +50,11 @@ int stream_prepare(mcalf_ctx* ctx, int mode, int64_t batch) {
         // (the generation count goes on: the new stamps are zero and no launch is ever stamped 0, while a count that
         // restarted could equal the completion word an earlier launch left in h_ctl[1])
     }
+    return ensure_ctl(ctx);
+}
+
+// The page-locked, device-mapped words a launch and the host exchange (h_ctl: see host_ctx.h).
+int ensure_ctl(mcalf_ctx* ctx) {
     if (!ctx->h_ctl) {
         HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_ctl, kCtlWords * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset((void*)ctx->h_ctl, 0, kCtlWords * sizeof(unsigned int));

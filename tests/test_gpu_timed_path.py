@@ -279,7 +279,8 @@ def test_streaming_host_entry_one_launch_no_copy_commands(cfg, conv, n, monkeypa
                 assert ll.grid == 2 * torch.cuda.get_device_properties(0).multi_processor_count
                 assert ll.items == n * fit.info.ntiles
                 assert ll.stream_setup_wgs == -(-int(env.get("MCALF_STREAM_WGS", 16)) // 8) * 8    # (so many per XCD)
-                assert ll.stream_polled == (0 if (env.get("MCALF_STREAM_POLL") == "0" or fit.info.ntiles > 1) else 1)
+                # (completion read off the kernel's page-locked word; tiled spectra: the finalize kernel's word, round 6)
+                assert ll.stream_polled == (0 if env.get("MCALF_STREAM_POLL") == "0" else 1)
                 assert np.array_equal(got, ref["logl"]), (env, rep)
             opin = torch.full((n,), float("nan"), dtype=torch.float64).pin_memory().numpy()
             fit.loglike_batch(Ppin, out=opin)
@@ -352,7 +353,7 @@ def test_one_launch_variant_of_small_calls_gives_the_two_kernel_bits(cfg, conv, 
     big[:9] = P
     with mcalf_amd.als_fitter(None, **kw) as fit:
         got = fit.loglike_batch(big)
-        assert fit.last_launch().inline_setup == 0
+        assert fit.last_launch().inline_setup in (0, 2)          # (2: a zero-copy call that launched before it copied its rows)
     assert np.array_equal(got[:9], out[None][2])
 
 
@@ -445,3 +446,44 @@ def test_set_up_geometry_and_chunked_ordering_do_not_change_results(block, monke
         small = fit.loglike_batch(P[:700])                       # two-kernel path, not persistent
         assert fit.last_launch().persistent == 0 and fit.last_launch().inline_setup == 0
     assert np.array_equal(got, ref) and np.array_equal(small, ref[:700])
+
+
+def test_small_call_that_launches_before_it_copies_its_rows(monkeypatch):
+    """Config B's step through host pointers (1024 rows, 200 KB: MCALF_PATH_HOST_ZEROCOPY): the kernels are launched
+    BEFORE the host copies the rows into the page-locked block they are read from, and the set-up kernel's workgroups
+    wait for the host's row count -- launch latency and copy overlap (`inline_setup` == 2).  Same bits as the device
+    entry, as the copy-first form (MCALF_SMALL_GATE=0), for logL, chi2 and the unit-cube entry; calls below 32 KB and the
+    one-launch variant copy first as before; repeated calls of different sizes reuse the block."""
+    kw, batch, seed = workloads.config("B", oracle_synth)
+    P = workloads.draw_P(kw, batch, np.random.default_rng(seed))
+    dP = torch.from_numpy(P).cuda()
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        want = _device_logl(fit, dP, batch)
+        for _ in range(3):
+            assert np.array_equal(fit.loglike_batch(P), want)
+            ll = fit.last_launch()
+            assert (ll.path, ll.inline_setup, ll.stream_polled, ll.stream_fallback) == (_lib.MCALF_PATH_HOST_ZEROCOPY, 2, 1, 0)
+        assert np.array_equal(fit.loglike_batch(P[:700]), want[:700]) and fit.last_launch().inline_setup == 2
+        assert np.array_equal(fit.loglike_batch(P[:300]), want[:300]) and fit.last_launch().inline_setup == 1   # one-launch variant
+        assert np.array_equal(fit.loglike_batch(P[:3]), want[:3]) and fit.last_launch().inline_setup == 1
+        chi2 = fit.chi2_batch(P)
+        assert fit.last_launch().inline_setup == 2
+        cubes = np.random.default_rng(8).random((batch, fit.ndim))
+        theta, ll_cube = fit.loglike_cube_batch(cubes)
+        assert fit.last_launch().inline_setup == 2
+        assert np.array_equal(ll_cube, fit.loglike_batch(theta))
+    monkeypatch.setenv("MCALF_SMALL_GATE", "0")
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        assert np.array_equal(fit.loglike_batch(P), want) and fit.last_launch().inline_setup == 0
+        assert np.array_equal(fit.chi2_batch(P), chi2)
+        assert " small_gate=0 " in fit.get_config()
+    # a persistent, ordered launch inside the small path (2300 rows x 25 parameters < 65536 doubles): the ordering workgroup
+    # of the set-up kernel waits for every row
+    monkeypatch.delenv("MCALF_SMALL_GATE")
+    monkeypatch.setenv("MCALF_STREAM", "0")
+    P2 = workloads.draw_P(kw, 2300, np.random.default_rng(seed + 5))
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        got = fit.loglike_batch(P2)
+        ll = fit.last_launch()
+        assert (ll.path, ll.inline_setup, ll.persistent, ll.ordered) == (_lib.MCALF_PATH_HOST_ZEROCOPY, 2, 1, 1)
+        assert np.array_equal(got, _device_logl(fit, torch.from_numpy(P2).cuda(), 2300))
