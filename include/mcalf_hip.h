@@ -268,8 +268,9 @@ static inline double mcalf_mailbox_call(void* box, const double* theta, int32_t 
 /* Row blocks a batch is issued in (0 = automatic [default], n <= 8 = exactly n).  Automatic means ONE block
  * for the *_device entries (the persistent fused kernel leaves no launch tail worth filling; measured) and, for
  * the host-pointer entries with large batches, ONE streaming launch (MCALF_PATH_HOST_STREAM: spectra that fit one pixel
- * tile; MCALF_STREAM=2 streams tiled ones too; an explicit block count, MCALF_STREAM=0, a tiled spectrum or a launch
- * below the persistent-grid threshold selects the row-block pipeline instead: a first block of
+ * tile, and tiled ones up to 32768 work items -- live points x tiles; MCALF_STREAM=2 streams larger tiled batches too; an
+ * explicit block count, MCALF_STREAM=0, a larger tiled batch or a launch below the persistent-grid threshold selects the
+ * row-block pipeline instead: a first block of
  * 128 KiB of parameter rows (MCALF_HOST_FIRST_KB; twice that for page-locked input), every following block twice the one
  * before, the last one taking the rest, so that the GPU starts after ~10 us of staging and block k+1's staging copy,
  * H2D copy and per-sample set-up run under block k's kernel).  With more than one block in a *_device call the
@@ -314,8 +315,6 @@ typedef struct {
     int32_t pinned_in;      /* host-pointer entries: the parameter rows were page-locked caller memory        */
     int32_t pinned_out;     /* host-pointer entries: the result array was page-locked caller memory           */
     int32_t inline_setup;   /* 1: small launch -- ONE kernel, the per-sample set-up ran inside the fused kernel;
-                               2: MCALF_PATH_HOST_ZEROCOPY call that launched BEFORE it copied its rows (>= 32 KB of them): the
-                                  set-up kernel waited for the host's row count, launch latency and copy overlapped;
                                3: no launch at all -- the context's resident evaluator answered (mcalf_set_resident) */
     int32_t ordered;        /* 1: the persistent grid handed the live points out sorted by component count      */
     int32_t stream_setup_wgs; /* MCALF_PATH_HOST_STREAM: workgroups of the grid dedicated to the set-up while rows were outstanding */

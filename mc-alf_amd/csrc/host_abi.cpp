@@ -530,7 +530,7 @@ int launch_finalize(mcalf_ctx* ctx, const KArgs& a, int64_t nrows, int mode, hip
 
 static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0, int64_t nrows, int chunk,
                         int targonly, int onecomp_fill, double* d_out, double* d_model, hipStream_t stream,
-                        bool from_cube, double* d_theta, bool timed_ok, int wide_stage = kWideNone, bool gated = false) {
+                        bool from_cube, double* d_theta, bool timed_ok, int wide_stage = kWideNone) {
     const bool reduces = (mode == kModeLogL || mode == kModeChi2);
     KArgs a = make_kargs(ctx, mode, dP, row0, nrows, chunk, targonly, onecomp_fill, d_out, d_model, from_cube, d_theta, wide_stage);
     // Persistent grid = the workgroup slots of the chip (2 per CU: LDS and the 4 waves per SIMD the kernel's
@@ -553,10 +553,6 @@ static int launch_range(mcalf_ctx* ctx, int mode, const double* dP, int64_t row0
     // gap behind it are a fifth of such a call's latency.  Same set-up code, same bits.
     const bool inl = !a.persist && a.nitems <= ctx->inline_max_items;
     ctx->last.inline_setup = inl ? 1 : 0;
-    if (gated) {                                          // (run_host_small checked that this launch has a set-up kernel)
-        if (inl) return set_err(ctx, MCALF_ERR_INVALID, "internal: a gated launch needs the set-up kernel");
-        a.arrived = ctx->d_ctl + kCtlArrived; a.status = ctx->d_ctl; a.spin_ticks = (long long)(ctx->stream_timeout_s * 1e8);
-    }
     if (!inl) {
         const int per_wg = ctx->setup_block / 64;             // live points per set-up workgroup (one wave each)
         const dim3 sgrid((unsigned)((nrows + per_wg - 1) / per_wg) + (a.order ? 1u : 0u)), sblock((unsigned)ctx->setup_block);
@@ -686,7 +682,7 @@ static int launch_wide(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch
 }
 
 int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill,
-           double* d_out, double* d_model, hipStream_t stream, bool from_cube, double* d_theta, bool gated) {
+           double* d_out, double* d_model, hipStream_t stream, bool from_cube, double* d_theta) {
     if (batch == 0) return MCALF_OK;
     int rc;
     if (ctx->wide) return launch_wide(ctx, mode, dP, batch, targonly, onecomp_fill, d_out, d_model, stream, from_cube, d_theta);
@@ -708,8 +704,7 @@ int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targon
     ctx->last.row_blocks = nchunks;
     if (nchunks == 1)
         return launch_range(ctx, mode, dP, 0, batch, 0, targonly, onecomp_fill, d_out, d_model, stream, from_cube,
-                            d_theta, true, kWideNone, gated);
-    if (gated) return set_err(ctx, MCALF_ERR_INVALID, "internal: a gated launch is ONE row block");
+                            d_theta, true);
     if ((rc = ensure_aux(ctx, nchunks - 1))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, stream));
     for (int c = 0; c < nchunks; ++c) {
@@ -804,7 +799,8 @@ bool is_pinned_host(const void* p) {
 // helper took over, enqueueing (H2D commands + launches), the wait for the streams, the copy of the results.
 namespace {
 struct HostTrace { double stage_us = 0, stage_bytes = 0, helper_bytes = 0, helper_wait_us = 0, enqueue_us = 0, wait_us = 0, out_us = 0, first_enqueued_us = 0;
-                   double call_copy_us = 0, call_order_us = 0, call_launch_us = 0, call_copy_max = 0; long calls = 0, blocks = 0; };
+                   double call_copy_us = 0, call_order_us = 0, call_launch_us = 0, call_copy_max = 0; long calls = 0, blocks = 0;
+                   double small_prep_us = 0, small_launch_us = 0, small_copy_us = 0, small_poll_us = 0, small_out_us = 0; long small_calls = 0; };
 HostTrace g_host_trace;
 // MCALF_HOST_TRACE=2: additionally the GPU-side timeline of the LAST pipelined call -- per row block the times (us after the
 // call began) at which its H2D copy started and ended and its kernels ended on the device, and when the host enqueued it
@@ -835,6 +831,14 @@ int stage_from_back(void*, int64_t, int64_t, void* arg) {
 }  // namespace
 
 void host_trace_report(const mcalf_ctx* ctx) {
+    if (ctx->host_trace && g_host_trace.small_calls > 0) {
+        const HostTrace& t = g_host_trace;
+        const double n = (double)t.small_calls;
+        std::fprintf(stderr, "mcalf host trace (zero-copy small calls, %ld calls; us per call): copy into the page-locked block %.2f, launch calls %.2f, "
+                     "theta rows on the host %.2f, wait for the results %.2f, results out %.2f\n", t.small_calls,
+                     t.small_prep_us / n, t.small_launch_us / n, t.small_copy_us / n, t.small_poll_us / n, t.small_out_us / n);
+        if (g_host_trace.calls == 0) g_host_trace = HostTrace();
+    }
     if (!ctx->host_trace || g_host_trace.calls == 0) return;
     const HostTrace& t = g_host_trace;
     const double n = (double)t.calls;
@@ -1049,25 +1053,16 @@ int ensure_small(mcalf_ctx* ctx) {
 // Small scalar-output calls (up to kSmallDoubles parameters: single-theta calls, config B's batch), zero-copy: a
 // single-theta call is dominated by the latency of its two copy commands.  from_cube / theta_out: as in run_host_stream.
 static int run_host_small(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, int targonly, int fill,
-                          double* out_scalar, bool from_cube, double* theta_out, bool gate_ok = true) {
+                          double* out_scalar, bool from_cube, double* theta_out) {
     int rc;
     if (resident_serves(ctx, mode, batch, rowlen, from_cube)) return resident_call(ctx, P, rowlen, out_scalar);
     if ((rc = ensure_small(ctx))) return rc;
-    // Launch first, copy afterwards (a call of at least 32 KB of rows whose launch has a set-up kernel: config B's 1024 rows):
-    // the set-up kernel's workgroups wait for the host's row count, so the launch latency (~5 us) runs under the copy (~4 us
-    // per 200 KB) instead of behind it.  Smaller calls -- the one-theta callables -- copy first: there is nothing to overlap.
-    const int64_t nitems = batch * ctx->ntiles;
-    const bool has_setup = (ctx->persist && nitems >= 4LL * 2 * ctx->num_cu) || nitems > ctx->inline_max_items;
-    const bool gated = gate_ok && ctx->small_gate && has_setup && !ctx->wide && !ctx->profiling && pick_chunks(ctx, batch) == 1 &&
-                       (size_t)batch * rowlen * sizeof(double) >= 32768 && !ctx->stream_device;
-    if (gated) {
-        if ((rc = ensure_ctl(ctx))) return rc;
-        ctx->h_ctl[0] = 0u;
-        ctx->h_ctl[kCtlArrived] = 0u;
-        __atomic_thread_fence(__ATOMIC_SEQ_CST);
-    } else {
-        std::memcpy(ctx->h_small, P, (size_t)batch * rowlen * sizeof(double));
-    }
+    const bool trace = ctx->host_trace != 0;
+    const double ts0 = trace ? now_us() : 0.0;
+    // (Copy first, launch afterwards.  Round 6 tried the other order for calls of >= 32 KB -- the set-up kernel's workgroups
+    // waiting for the host's row count, so that the launch latency would run under the copy: the copy of config B's 200 KB
+    // takes 1.5 us, the waits' PCIe looks cost 8 us; docs/optimisation_log.md 8f.)
+    std::memcpy(ctx->h_small, P, (size_t)batch * rowlen * sizeof(double));
     ctx->last.path = MCALF_PATH_HOST_ZEROCOPY; ctx->last.pinned_in = ctx->last.pinned_out = 0; ctx->last.stream_fallback = 0;
     // Completion is read off the results: their slots are filled with a NaN no kernel produces, and the call is over
     // when none is left -- a stream wait costs an interrupt and a thread wake-up on top of the kernel, a fifth of a
@@ -1076,18 +1071,12 @@ static int run_host_small(mcalf_ctx* ctx, int mode, const double* P, int64_t bat
     const bool poll = ctx->stream_poll != 0;
     if (poll)
         for (int64_t i = 0; i < batch; ++i) __atomic_store_n(res + i, kResultPending, __ATOMIC_RELEASE);
-    rc = launch(ctx, mode, ctx->d_small, batch, targonly, fill, ctx->d_small + kSmallDoubles, nullptr, ctx->stream, from_cube, nullptr, gated);
+    const double ts1 = trace ? now_us() : 0.0;
+    rc = launch(ctx, mode, ctx->d_small, batch, targonly, fill, ctx->d_small + kSmallDoubles, nullptr, ctx->stream, from_cube);
     if (rc) return rc;
-    if (gated) {                                          // (nothing between the launch and the last publication can fail)
-        ctx->last.inline_setup = 2;
-        constexpr int64_t kRowsPerStep = 128;
-        for (int64_t r0 = 0; r0 < batch; r0 += kRowsPerStep) {
-            const int64_t n = std::min(kRowsPerStep, batch - r0);
-            std::memcpy(ctx->h_small + (size_t)r0 * rowlen, P + (size_t)r0 * rowlen, (size_t)n * rowlen * sizeof(double));
-            __atomic_store_n(const_cast<unsigned int*>(ctx->h_ctl + kCtlArrived), (unsigned int)(r0 + n), __ATOMIC_RELEASE);
-        }
-    }
+    const double ts2 = trace ? now_us() : 0.0;
     if (theta_out) host_scale_cube(ctx, P, batch, theta_out);       // (under the launch)
+    const double ts3 = trace ? now_us() : 0.0;
     bool done = false;
     if (poll) {
         int64_t left = batch;                            // results [left, batch) have been seen
@@ -1100,12 +1089,13 @@ static int run_host_small(mcalf_ctx* ctx, int mode, const double* P, int64_t bat
     }
     if (!done) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->last.stream_polled = done ? 1 : 0;
-    if (gated && ctx->h_ctl[0] != 0u) {                   // a wait for the rows ran out inside the set-up kernel: the plain way
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->last.stream_fallback = MCALF_STREAM_FALLBACK_TIMEOUT;
-        return run_host_small(ctx, mode, P, batch, rowlen, targonly, fill, out_scalar, from_cube, theta_out, false);
-    }
+    const double ts4 = trace ? now_us() : 0.0;
     std::memcpy(out_scalar, ctx->h_small + kSmallDoubles, (size_t)batch * sizeof(double));
+    if (trace) {
+        HostTrace& t = g_host_trace;
+        t.small_calls++; t.small_prep_us += ts1 - ts0; t.small_launch_us += ts2 - ts1; t.small_copy_us += ts3 - ts2;
+        t.small_poll_us += ts4 - ts3; t.small_out_us += now_us() - ts4;
+    }
     return MCALF_OK;
 }
 

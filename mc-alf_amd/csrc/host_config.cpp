@@ -44,7 +44,6 @@ EnvKnobs read_environment() {
     if (env_int("MCALF_STREAM_CHUNK", &v)) k.stream_chunk = std::min(std::max(v & ~7, 8), 512);
     if (env_int("MCALF_STREAM_DEVICE", &v)) k.stream_device = std::min(std::max(v, 0), 2);
     if (env_int("MCALF_STREAM_TRACE", &v)) k.stream_trace = v != 0;
-    if (env_int("MCALF_SMALL_GATE", &v)) k.small_gate = v != 0;
     if (const char* e = std::getenv("MCALF_STREAM_TIMEOUT")) {
         const double t = std::atof(e);
         if (t > 0.0 && t <= 60.0) k.stream_timeout_s = t;
@@ -79,7 +78,6 @@ void apply_environment(mcalf_ctx* ctx) {
     if (k.stream_chunk >= 0) ctx->stream_chunk = k.stream_chunk;
     if (k.stream_device >= 0) ctx->stream_device = k.stream_device;
     if (k.stream_trace >= 0) ctx->stream_trace = k.stream_trace;
-    if (k.small_gate >= 0) ctx->small_gate = k.small_gate;
     if (k.stream_timeout_s > 0.0) ctx->stream_timeout_s = k.stream_timeout_s;
     if (k.chunks >= 0) ctx->chunks_req = k.chunks;
 #ifdef MCALF_TESTING
@@ -104,7 +102,7 @@ extern "C" int mcalf_get_config(const mcalf_ctx* ctx, char* buf, int64_t n) {
     add("stream=%d stream_min=%d stream_wgs=%d stream_poll=%d stream_eager=%d stream_chunk=%d stream_device=%d stream_trace=%d stream_timeout_s=%g ",
         ctx->stream_on, ctx->stream_min, ctx->stream_wgs, ctx->stream_poll, ctx->stream_eager, ctx->stream_chunk, ctx->stream_device, ctx->stream_trace,
         ctx->stream_timeout_s);
-    add("small_gate=%d xcd_mask=0x%x cu_mask_words=%d wide_lsf=%d", ctx->small_gate, ctx->xcd_mask, (int)ctx->cu_mask.size(), ctx->wide);
+    add("xcd_mask=0x%x cu_mask_words=%d wide_lsf=%d", ctx->xcd_mask, (int)ctx->cu_mask.size(), ctx->wide);
     s += " [env:";
     auto named = [&](bool set, const char* name) { if (set) { s += ' '; s += name; } };
     named(k.lines_per_sync >= 0, "MCALF_LINES_PER_SYNC"); named(k.persist >= 0, "MCALF_PERSIST"); named(k.order >= 0, "MCALF_ORDER");
@@ -112,7 +110,7 @@ extern "C" int mcalf_get_config(const mcalf_ctx* ctx, char* buf, int64_t n) {
     named(k.host_plan_n > 0, "MCALF_HOST_PLAN"); named(k.host_first_kb >= 0, "MCALF_HOST_FIRST_KB"); named(k.host_trace >= 0, "MCALF_HOST_TRACE");
     named(k.stage_threads >= 0, "MCALF_STAGE_THREADS"); named(k.stream >= 0, "MCALF_STREAM"); named(k.stream_min >= 0, "MCALF_STREAM_MIN"); named(k.stream_wgs >= 0, "MCALF_STREAM_WGS");
     named(k.stream_poll >= 0, "MCALF_STREAM_POLL"); named(k.stream_eager >= 0, "MCALF_STREAM_EAGER"); named(k.stream_chunk >= 0, "MCALF_STREAM_CHUNK");
-    named(k.stream_device >= 0, "MCALF_STREAM_DEVICE"); named(k.stream_trace >= 0, "MCALF_STREAM_TRACE"); named(k.small_gate >= 0, "MCALF_SMALL_GATE");
+    named(k.stream_device >= 0, "MCALF_STREAM_DEVICE"); named(k.stream_trace >= 0, "MCALF_STREAM_TRACE");
     named(k.stream_timeout_s > 0.0, "MCALF_STREAM_TIMEOUT"); named(k.chunks >= 0, "MCALF_CHUNKS"); named(!k.rccl_lib.empty(), "MCALF_RCCL_LIB");
     if (s.back() == ':') s += " none";
     s += "]";

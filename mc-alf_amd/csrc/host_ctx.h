@@ -31,6 +31,7 @@
 namespace mcalf {
 constexpr int kMaxChunks = 8;
 constexpr size_t kSmallDoubles = 65536;     // up to 512 KB of parameters (and as many results) go the zero-copy way
+constexpr int64_t kStreamTiledMaxItems = 32768;   // tiled spectra stream up to this many work items (host_stream.cpp: run_host_stream)
 }  // namespace mcalf
 using namespace mcalf;
 
@@ -115,7 +116,6 @@ struct EnvKnobs {
     int stream_chunk = -1;                  // MCALF_STREAM_CHUNK     8 .. 512, a multiple of 8
     int stream_device = -1;                 // MCALF_STREAM_DEVICE    0 / 1 / 2
     int stream_trace = -1;                  // MCALF_STREAM_TRACE     0 / 1
-    int small_gate = -1;                    // MCALF_SMALL_GATE       0 / 1
     double stream_timeout_s = -1.0;         // MCALF_STREAM_TIMEOUT   seconds, (0, 60]
     int chunks = -1;                        // MCALF_CHUNKS           0 .. 8
     std::string rccl_lib;                   // MCALF_RCCL_LIB         (read when the first mcalf_comm_* call loads RCCL)
@@ -232,14 +232,13 @@ struct mcalf_ctx {
     // (stream_probe_xcds: mcalf_create, mcalf_set_cu_mask).  The streaming launch is built for exactly 0xFF.
     unsigned int xcd_mask = 0;
     std::vector<uint32_t> cu_mask;          // mcalf_set_cu_mask: the CU mask of the context's own streams (empty: none)
-    int stream_on = 1;                      // MCALF_STREAM: 0 = the row-block pipeline of round 2 instead; 1 = automatic (spectra that
-                                            // fit one tile: measured, config E's five tiles per live point run 1.3 % faster through
-                                            // the pipeline); 2 = always
+    int stream_on = 1;                      // MCALF_STREAM: 0 = the row-block pipeline of round 2 instead; 1 = automatic (spectra that fit
+                                            // one tile always, tiled ones up to kStreamTiledMaxItems work items: measured, config E's
+                                            // 16384 x 5 items run 2 % faster through the pipeline, 2048 x 5 items 10 % slower); 2 = always
     int stream_min = 4;                     // MCALF_STREAM_MIN: work items per workgroup slot from which a host-pointer batch streams
     int stream_wgs = 16;                    // MCALF_STREAM_WGS: workgroups dedicated to the set-up while rows are outstanding
     int stream_eager = 0;                   // MCALF_STREAM_EAGER: blocks of 8 rows per XCD any workgroup may set up (0: what the first items need)
     int stream_chunk = 32;                  // MCALF_STREAM_CHUNK: rows such a workgroup claims (and copies to HBM) at a time
-    int small_gate = 1;                     // MCALF_SMALL_GATE=0: zero-copy small calls copy their rows BEFORE they launch (1: launch, then copy)
     int stream_trace = 0;                   // MCALF_STREAM_TRACE=1 (diagnostic): host-side time per phase of the streaming entry
     int stream_device = 0;                  // MCALF_STREAM_DEVICE=1 (diagnostic): the *_device scalar entries take the streaming launch too
     int stream_poll = 1;                    // MCALF_STREAM_POLL=0: wait for the stream's signal instead of polling h_ctl[1]
@@ -296,9 +295,8 @@ enum { kWideNone = 0, kWideFused = 1, kWideKernels = 2 };
 KArgs make_kargs(const mcalf_ctx* ctx, int mode, const double* dP, int64_t row0, int64_t nrows, int chunk, int targonly,
                  int onecomp_fill, double* d_out, double* d_model, bool from_cube, double* d_theta, int wide_stage = kWideNone);
 // Enqueue one batch on `stream` (asynchronous): set-up kernel, fused kernel, finalize when tiled.
-// gated: the set-up kernel waits for the host's row count (h_ctl[kCtlArrived]) -- run_host_small launches before it copies
 int launch(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill, double* d_out,
-           double* d_model, hipStream_t stream, bool from_cube = false, double* d_theta = nullptr, bool gated = false);
+           double* d_model, hipStream_t stream, bool from_cube = false, double* d_theta = nullptr);
 // Everything of a launch that can fail WITHOUT anything having been enqueued (range check, workspace growth).
 int launch_preflight(mcalf_ctx* ctx, int mode, int64_t batch);
 int launch_finalize(mcalf_ctx* ctx, const KArgs& a, int64_t nrows, int mode, hipStream_t stream, int nparts = 0, bool signal = false);

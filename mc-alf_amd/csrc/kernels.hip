@@ -544,36 +544,14 @@ __global__ __launch_bounds__(kSetupBlockMax) void mcalf_sample_kernel(const KArg
     // one WAVE per live point, blockDim.x / 64 live points per workgroup (the waves never synchronise); with an
     // ordered hand-out workgroup 0 builds the order and the live points start at workgroup 1
     int blk = blockIdx.x;
-    const bool orders = a.order && blk == 0;
-    if (a.order && blk > 0) --blk;
-    const long s = (long)blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (!orders && s == 0 && lane == 0) *a.queue = 0u;  // item queue of the fused kernel that follows on the stream
-    // Gated small call (host_abi.cpp: run_host_small): the kernels were launched BEFORE the host copied the rows into the
-    // page-locked block they are read from -- the launch latency and the copy overlap -- and the host publishes its row
-    // count as it goes (a.arrived; rows arrive in order).  Thread 0 waits for the workgroup's last row (the ordering
-    // workgroup: for all of them); a wait that runs out (a.spin_ticks) raises a.status[0], the rows are published as
-    // unusable and the host repeats the call the plain way.
-    if (a.arrived) {
-        __shared__ int sOk;
-        if (threadIdx.x == 0) {
-            const long last = orders ? batch - 1 : min((long)(blk + 1) * (long)(blockDim.x >> 6), batch) - 1;
-            unsigned seen = 0u;
-            sOk = stream_wait_arrived(a, (unsigned)last, seen) ? 1 : 0;
-        }
-        __syncthreads();
-        if (!sOk) {
-            if (!orders && s < batch && lane == 0) {
-                SampleHdr h;
-                h.cont = 0.0; h.bot = 1.0; h.ncl = 0; h.n = 0; h.bad = 1; h.ngeneral = 0;
-                a.hdr[s] = h;
-            }
-            if (orders) for (long i = threadIdx.x; i < batch; i += blockDim.x) a.order[i] = (int)i;
-            return;
-        }
+    if (a.order) {
+        if (blk == 0) { build_order<kZeroPad>(a, batch); return; }
+        --blk;
     }
-    if (orders) { build_order<kZeroPad>(a, batch); return; }
+    const long s = (long)blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (s >= batch) return;
+    const int lane = threadIdx.x & 63;
+    if (s == 0 && lane == 0) *a.queue = 0u;          // item queue of the fused kernel that follows on the stream
     setup_sample<kZeroPad>(a, s, lane, a.recs + (size_t)s * a.ncl_cap * kRecStride,
                            a.taps + (a.taps_shared ? 0 : (size_t)s * (2 * a.n_cap + 8)), !a.taps_shared || s == 0, a.hdr + s, true);
 }

@@ -242,11 +242,16 @@ def test_streaming_host_entry_one_launch_no_copy_commands(cfg, conv, n, monkeypa
     P = workloads.draw_P(kw, n, np.random.default_rng(seed + 77), damped=2 if cfg == "E" else 0)
     assert P.size > 65536
     if cfg == "E":
-        # a tiled spectrum takes the row-block pipeline by default (measured faster); MCALF_STREAM=2 streams it as well
+        # a tiled spectrum streams up to 32768 work items (1400 x 5 here) and takes the row-block pipeline beyond (measured:
+        # profiles/r06_tiled_stream_crossover.txt); MCALF_STREAM=2 streams every size
         with mcalf_amd.als_fitter(None, **kw) as fit:
             require_streaming_shape(fit)
-            fit.loglike_batch(P)
+            small_tiled = fit.loglike_batch(P)
+            assert fit.last_launch().path == _lib.MCALF_PATH_HOST_STREAM
+            big = np.ascontiguousarray(np.tile(P, (5, 1)))                     # 7000 x 5 = 35000 work items
+            big_ll = fit.loglike_batch(big)
             assert fit.last_launch().path == _lib.MCALF_PATH_HOST_PIPELINED
+            assert np.array_equal(big_ll[:n], small_tiled) and np.array_equal(big_ll[-n:], small_tiled)
         monkeypatch.setenv("MCALF_STREAM", "2")
     Ppin = torch.from_numpy(P).pin_memory().numpy()
     dP = torch.from_numpy(P).cuda()
@@ -353,7 +358,7 @@ def test_one_launch_variant_of_small_calls_gives_the_two_kernel_bits(cfg, conv, 
     big[:9] = P
     with mcalf_amd.als_fitter(None, **kw) as fit:
         got = fit.loglike_batch(big)
-        assert fit.last_launch().inline_setup in (0, 2)          # (2: a zero-copy call that launched before it copied its rows)
+        assert fit.last_launch().inline_setup == 0
     assert np.array_equal(got[:9], out[None][2])
 
 
@@ -447,43 +452,3 @@ def test_set_up_geometry_and_chunked_ordering_do_not_change_results(block, monke
         assert fit.last_launch().persistent == 0 and fit.last_launch().inline_setup == 0
     assert np.array_equal(got, ref) and np.array_equal(small, ref[:700])
 
-
-def test_small_call_that_launches_before_it_copies_its_rows(monkeypatch):
-    """Config B's step through host pointers (1024 rows, 200 KB: MCALF_PATH_HOST_ZEROCOPY): the kernels are launched
-    BEFORE the host copies the rows into the page-locked block they are read from, and the set-up kernel's workgroups
-    wait for the host's row count -- launch latency and copy overlap (`inline_setup` == 2).  Same bits as the device
-    entry, as the copy-first form (MCALF_SMALL_GATE=0), for logL, chi2 and the unit-cube entry; calls below 32 KB and the
-    one-launch variant copy first as before; repeated calls of different sizes reuse the block."""
-    kw, batch, seed = workloads.config("B", oracle_synth)
-    P = workloads.draw_P(kw, batch, np.random.default_rng(seed))
-    dP = torch.from_numpy(P).cuda()
-    with mcalf_amd.als_fitter(None, **kw) as fit:
-        want = _device_logl(fit, dP, batch)
-        for _ in range(3):
-            assert np.array_equal(fit.loglike_batch(P), want)
-            ll = fit.last_launch()
-            assert (ll.path, ll.inline_setup, ll.stream_polled, ll.stream_fallback) == (_lib.MCALF_PATH_HOST_ZEROCOPY, 2, 1, 0)
-        assert np.array_equal(fit.loglike_batch(P[:700]), want[:700]) and fit.last_launch().inline_setup == 2
-        assert np.array_equal(fit.loglike_batch(P[:300]), want[:300]) and fit.last_launch().inline_setup == 1   # one-launch variant
-        assert np.array_equal(fit.loglike_batch(P[:3]), want[:3]) and fit.last_launch().inline_setup == 1
-        chi2 = fit.chi2_batch(P)
-        assert fit.last_launch().inline_setup == 2
-        cubes = np.random.default_rng(8).random((batch, fit.ndim))
-        theta, ll_cube = fit.loglike_cube_batch(cubes)
-        assert fit.last_launch().inline_setup == 2
-        assert np.array_equal(ll_cube, fit.loglike_batch(theta))
-    monkeypatch.setenv("MCALF_SMALL_GATE", "0")
-    with mcalf_amd.als_fitter(None, **kw) as fit:
-        assert np.array_equal(fit.loglike_batch(P), want) and fit.last_launch().inline_setup == 0
-        assert np.array_equal(fit.chi2_batch(P), chi2)
-        assert " small_gate=0 " in fit.get_config()
-    # a persistent, ordered launch inside the small path (2300 rows x 25 parameters < 65536 doubles): the ordering workgroup
-    # of the set-up kernel waits for every row
-    monkeypatch.delenv("MCALF_SMALL_GATE")
-    monkeypatch.setenv("MCALF_STREAM", "0")
-    P2 = workloads.draw_P(kw, 2300, np.random.default_rng(seed + 5))
-    with mcalf_amd.als_fitter(None, **kw) as fit:
-        got = fit.loglike_batch(P2)
-        ll = fit.last_launch()
-        assert (ll.path, ll.inline_setup, ll.persistent, ll.ordered) == (_lib.MCALF_PATH_HOST_ZEROCOPY, 2, 1, 1)
-        assert np.array_equal(got, _device_logl(fit, torch.from_numpy(P2).cuda(), 2300))
