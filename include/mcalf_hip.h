@@ -268,7 +268,7 @@ static inline double mcalf_mailbox_call(void* box, const double* theta, int32_t 
 /* Row blocks a batch is issued in (0 = automatic [default], n <= 8 = exactly n).  Automatic means ONE block
  * for the *_device entries (the persistent fused kernel leaves no launch tail worth filling; measured) and, for
  * the host-pointer entries with large batches, ONE streaming launch (MCALF_PATH_HOST_STREAM: spectra that fit one pixel
- * tile, and tiled ones up to 32768 work items -- live points x tiles; MCALF_STREAM=2 streams larger tiled batches too; an
+ * tile, and tiled ones up to 65536 work items -- live points x tiles; MCALF_STREAM=2 streams larger tiled batches too; an
  * explicit block count, MCALF_STREAM=0, a larger tiled batch or a launch below the persistent-grid threshold selects the
  * row-block pipeline instead: a first block of
  * 128 KiB of parameter rows (MCALF_HOST_FIRST_KB; twice that for page-locked input), every following block twice the one

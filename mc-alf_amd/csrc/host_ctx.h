@@ -31,7 +31,7 @@
 namespace mcalf {
 constexpr int kMaxChunks = 8;
 constexpr size_t kSmallDoubles = 65536;     // up to 512 KB of parameters (and as many results) go the zero-copy way
-constexpr int64_t kStreamTiledMaxItems = 32768;   // tiled spectra stream up to this many work items (host_stream.cpp: run_host_stream)
+constexpr int64_t kStreamTiledMaxItems = 65536;   // tiled spectra stream up to this many work items (host_stream.cpp: run_host_stream)
 }  // namespace mcalf
 using namespace mcalf;
 
@@ -234,7 +234,7 @@ struct mcalf_ctx {
     std::vector<uint32_t> cu_mask;          // mcalf_set_cu_mask: the CU mask of the context's own streams (empty: none)
     int stream_on = 1;                      // MCALF_STREAM: 0 = the row-block pipeline of round 2 instead; 1 = automatic (spectra that fit
                                             // one tile always, tiled ones up to kStreamTiledMaxItems work items: measured, config E's
-                                            // 16384 x 5 items run 2 % faster through the pipeline, 2048 x 5 items 10 % slower); 2 = always
+                                            // 16384 x 5 items run 0.5 % faster through the pipeline, 8192 x 5 items 3 % slower); 2 = always
     int stream_min = 4;                     // MCALF_STREAM_MIN: work items per workgroup slot from which a host-pointer batch streams
     int stream_wgs = 16;                    // MCALF_STREAM_WGS: workgroups dedicated to the set-up while rows are outstanding
     int stream_eager = 0;                   // MCALF_STREAM_EAGER: blocks of 8 rows per XCD any workgroup may set up (0: what the first items need)

@@ -216,9 +216,10 @@ int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
     if (!ctx->stream_on || ctx->chunks_req > 0 || ctx->host_plan_n > 0 || ctx->profiling || !stream_qualifies(ctx, batch)) return MCALF_OK;
     // Tiled spectra (automatic): the streaming launch up to kStreamTiledMaxItems work items, the row-block pipeline beyond.
     // Measured on MI355X, config E (5 tiles per live point), pageable rows, host step over the device-resident one:
-    // 2048 rows 1.12 streaming / 1.24 pipeline, 4096 rows 1.09 / 1.14, 8192 rows 1.08 / 1.09, 16384 rows 1.07 / 1.05 --
-    // the tiled streaming kernel itself runs 6.6 % behind the batch kernel with the rows resident (single-tile: 3.3 % at
-    // 32768 rows), the pipeline's cost is a fixed ~60-90 us of block boundaries (profiles/r06_tiled_stream_crossover.txt).
+    // 2048 rows 1.11 streaming (1.24 pipeline), 4096 rows 1.075 (1.14), 8192 rows 1.057 (1.09), 16384 rows 1.051 (1.045) --
+    // with the rows resident the tiled streaming kernel runs 4.3 % behind the batch kernel (single-tile: 3-4 % at 32768
+    // rows: per-XCD queues and stamps, workgroups that keep setting rows up), the pipeline's cost is a fixed ~60-90 us of
+    // block boundaries (profiles/r06_tiled_stream_crossover.txt).
     if (ctx->stream_on == 1 && ctx->ntiles > 1 && batch * (int64_t)ctx->ntiles > kStreamTiledMaxItems) return MCALF_OK;
     if (ctx->xcd_mask != (1u << kXcds) - 1u) {            // not the device shape the launch deals its rows for: see stream_probe_xcds
         ctx->last.stream_fallback = MCALF_STREAM_FALLBACK_SHAPE;

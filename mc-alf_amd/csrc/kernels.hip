@@ -921,7 +921,11 @@ __device__ __forceinline__ void fused_items(const KArgs& a, double* smem) {
         // ---- 2. tau for this thread's pixels ----------------------------------------------------
         __syncthreads();                                   // publishes sRec, sW, sT, sNext (and the header of the one-launch variant)
         if (kInline) hd = *sHdr;
-        const double cont = hd.cont, bot = hd.bot;
+        // (streaming instantiations: continuum and tap sum are the same in every lane -- say so, and they ride through the
+        // component loop in scalar registers; as vector values the tiled instantiation spilled them to scratch.  The batch
+        // instantiations are left as they were compiled in round 4: their register allocation is what was measured.)
+        const double cont = kStream ? __builtin_bit_cast(double, uniform64(__builtin_bit_cast(unsigned long long, hd.cont))) : hd.cont;
+        const double bot = kStream ? __builtin_bit_cast(double, uniform64(__builtin_bit_cast(unsigned long long, hd.bot))) : hd.bot;
         // (streaming launch: a wait that ran out may leave a header nobody wrote -- keep its counts inside the buffers)
         const int ncl = kStream ? min(max(hd.ncl, 0), a.ncl_cap) : hd.ncl, n = kStream ? min(max(hd.n, 0), a.n_cap) : hd.n;
         const bool bad = hd.bad != 0;

@@ -123,10 +123,10 @@ def test_cube_in_logl_out_matches_two_step_path_and_oracle():
     assert np.max(np.abs(logL[:40] - want)) < 1e-4
 
 
-@pytest.mark.parametrize("cfg,n,path", [("C", 4096, "stream"), ("C", 700, "small"), ("E", 1400, "stream"), ("E", 7000, "staged")])
+@pytest.mark.parametrize("cfg,n,path", [("C", 4096, "stream"), ("C", 700, "small"), ("E", 1400, "stream"), ("E", 13200, "staged")])
 def test_cube_host_entry_takes_the_fast_paths_of_the_theta_entry(cfg, n, path):
     """The host-pointer cube entry goes the ways of mcalf_loglike_batch -- ONE streaming launch for a large batch of a
-    single-tile spectrum and for a tiled one up to 32768 work items, the zero-copy small call below 512 KB of parameters
+    single-tile spectrum and for a tiled one up to 65536 work items, the zero-copy small call below 512 KB of parameters
     (completion read off the results), staged copies for a larger tiled batch -- with the prior transform applied while the rows are decoded and theta formed on the
     host under the launch: theta bit-equal to the numpy transform, logL bit-equal to the two-step path, both int() flavours."""
     kw, _, seed = workloads.config(cfg, oracle_synth)

@@ -242,13 +242,13 @@ def test_streaming_host_entry_one_launch_no_copy_commands(cfg, conv, n, monkeypa
     P = workloads.draw_P(kw, n, np.random.default_rng(seed + 77), damped=2 if cfg == "E" else 0)
     assert P.size > 65536
     if cfg == "E":
-        # a tiled spectrum streams up to 32768 work items (1400 x 5 here) and takes the row-block pipeline beyond (measured:
+        # a tiled spectrum streams up to 65536 work items (1400 x 5 here) and takes the row-block pipeline beyond (measured:
         # profiles/r06_tiled_stream_crossover.txt); MCALF_STREAM=2 streams every size
         with mcalf_amd.als_fitter(None, **kw) as fit:
             require_streaming_shape(fit)
             small_tiled = fit.loglike_batch(P)
             assert fit.last_launch().path == _lib.MCALF_PATH_HOST_STREAM
-            big = np.ascontiguousarray(np.tile(P, (5, 1)))                     # 7000 x 5 = 35000 work items
+            big = np.ascontiguousarray(np.tile(P, (10, 1)))                    # 14000 x 5 = 70000 work items
             big_ll = fit.loglike_batch(big)
             assert fit.last_launch().path == _lib.MCALF_PATH_HOST_PIPELINED
             assert np.array_equal(big_ll[:n], small_tiled) and np.array_equal(big_ll[-n:], small_tiled)
