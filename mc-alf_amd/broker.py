@@ -147,7 +147,8 @@ class LikelihoodBroker:
         self.v.lo[:] = [np.min(b) for b in fit.bounds]
         self.v.hi[:] = [np.max(b) for b in fit.bounds]
         self.v.hdr[1], self.v.hdr[2], self.v.hdr[3] = self.ndim, self.slots, int(fit.startind)
-        self.v.hdr[7] = os.getpid()                             # (the ranks watch this process: a server that dies raises no stop flag)
+        self.v.hdr[7] = os.getpid()                             # (the ranks watch the SERVING process -- serve() / serve_native() write their
+                                                                # own pid again: the loop may run in a forked child of this one)
         self.v.hdr[0] = _MAGIC_RESIDENT if self.resident_us > 0 else _MAGIC   # last: a client that sees the magic sees a complete header
         self._batch = np.empty((self.slots, self.ndim))
 
@@ -178,6 +179,7 @@ class LikelihoodBroker:
     def serve_native(self, idle_sleep_after: float = 0.05, max_seconds: float = 0.0) -> None:
         """The loop inside the library (mcalf_broker_serve): returns when the stop flag is raised, or after `max_seconds`."""
         from . import _lib
+        self.v.hdr[7] = os.getpid()                             # the process that serves (a server that dies raises no stop flag)
         base = C.addressof(C.c_char.from_buffer(self.shm.buf))
         ok = False
         try:
@@ -208,6 +210,7 @@ class LikelihoodBroker:
             native = self.resident_us > 0 or (self.native and stop_when is None)
         if native:
             return self.serve_native(idle_sleep_after)
+        self.v.hdr[7] = os.getpid()
         last = time.perf_counter()
         ok = False
         try:
@@ -253,11 +256,14 @@ class BrokerClient:
     """A solver rank's side: the likelihood callables of `als_fitter`, served by the broker `name` through slot `slot`
     (one slot per rank; MPI rank numbers do).  Holds no device context."""
 
-    def __init__(self, name: str, slot: int, timeout: float = 60.0, call_timeout: float | None = 120.0):
+    def __init__(self, name: str, slot: int, timeout: float = 60.0, call_timeout: float | None = 120.0, server_pid: int | None = None):
         """`timeout`: seconds to wait for the broker's block to appear.  `call_timeout`: seconds a single likelihood call may
         wait for its answer before it raises (None: for ever); independently of it a call raises as soon as the server
-        PROCESS is gone (its pid is in the header) -- a server that dies raises no stop flag."""
+        PROCESS is gone (its pid is in the header, read afresh at every check) -- a server that dies raises no stop flag.
+        `server_pid=0` turns the pid check off and leaves `call_timeout` alone to decide: for ranks in another PID namespace
+        than the server (containers), where the header's pid names nothing or somebody else."""
         self.call_timeout = call_timeout
+        self._watch_pid = server_pid
         t0 = time.time()
         while True:
             try:
@@ -273,7 +279,7 @@ class BrokerClient:
                 raise RuntimeError(f"no likelihood broker named {name!r}")
             time.sleep(0.01)
         self.ndim, self.slots, self.startind = int(hdr[1]), int(hdr[2]), int(hdr[3])
-        self.server_pid = int(hdr[7])
+        self.server_pid = int(hdr[7]) if server_pid is None else int(server_pid)
         if not (0 <= slot < self.slots):
             raise ValueError(f"slot {slot} outside the broker's {self.slots} slots")
         self.slot = int(slot)
@@ -329,6 +335,8 @@ class BrokerClient:
         if n == 0x4000:
             self._t_wait = time.monotonic()
             return
+        if self._watch_pid is None:
+            self.server_pid = int(self.v.hdr[7])                # (the serving loop writes its own pid when it starts: read it afresh)
         if self.server_pid and not _process_alive(self.server_pid):
             raise RuntimeError(f"the likelihood broker's process ({self.server_pid}) is gone")
         if self.call_timeout is not None and time.monotonic() - self._t_wait > self.call_timeout:

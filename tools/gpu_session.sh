@@ -12,8 +12,8 @@
 #   hostfloor          tools/host_floor.py: what a synchronous host-pointer step costs at best
 #   ab <cfg> [steps]   tools/abl_bench.sh over build/abl/lib_*.so
 #   hostgap [legs]     the host-pointer step against the device-resident one (bench.py --only-other-configs) under the
-#                      default plan and its alternatives, interleaved twice: old 1:1:2:4 plan, streaming launch for tiled
-#                      spectra, a staging helper thread, the one-launch variant for two rounds of workgroups
+#                      default plan and its alternatives, interleaved twice: row-block pipeline only, streaming launch for
+#                      every size, round 5's 1:1:2:4 row blocks
 recipe=${1:-tests}; tag=${2:-r06}; shift 2 2>/dev/null
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/$tag; mkdir -p "$out" build
@@ -83,11 +83,9 @@ PY
     : > "$out/hostgap.txt"
     for round in 1 2; do
       run default_$round A=0
-      run oldplan_$round MCALF_HOST_PLAN=1,1,2,4
-      run stream2_$round MCALF_STREAM=2
-      run helper1_$round MCALF_STAGE_THREADS=1
-      run bstream_$round MCALF_STREAM_MIN=2 MCALF_STREAM_EAGER=16
-      run bstream_wgs_$round MCALF_STREAM_MIN=2 MCALF_STREAM_WGS=64 MCALF_STREAM_CHUNK=8
+      run pipeline_$round MCALF_STREAM=0
+      run stream_all_$round MCALF_STREAM=2
+      run oldplan_$round MCALF_STREAM=0 MCALF_HOST_PLAN=1,1,2,4
     done
     cat "$out/hostgap.txt" ;;
   *) echo "unknown recipe $recipe"; exit 2 ;;

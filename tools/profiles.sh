@@ -3,8 +3,8 @@
 # command (one fused launch per step), the PMC passes (each --pmc set its own run, no trace domains), the
 # instruction-issue micro-benchmark; then the figures are merged into profiles/pmc.json / traffic.json (stamped with the
 # kernel-source hash) and the bench line is taken AGAIN, now carrying them (bench_with_counters.json).
-# Usage: tools/profiles.sh <config> <outdir> [steps] [round tag, default r05]
-cfg=${1:-C}; out=${2:-gpurun_out/prof_$cfg}; steps=${3:-50}; tag=${4:-r05}
+# Usage: tools/profiles.sh <config> <outdir> [steps] [round tag, default r06]
+cfg=${1:-C}; out=${2:-gpurun_out/prof_$cfg}; steps=${3:-50}; tag=${4:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
 timeout -k 10 600 python bench.py --config $cfg --steps $steps > "$out/bench.json" 2> "$out/bench.err" || echo "bench failed"
