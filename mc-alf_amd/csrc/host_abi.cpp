@@ -372,9 +372,21 @@ extern "C" int mcalf_last_launch(const mcalf_ctx* ctx, mcalf_launch_info_t* info
 }
 
 // A stream of the context: non-blocking, or -- with a CU mask (mcalf_set_cu_mask) -- restricted to the mask's CUs.
-int create_stream(mcalf_ctx* ctx, hipStream_t* out) {
-    if (ctx->cu_mask.empty()) HIP_TRY(ctx, hipStreamCreateWithFlags(out, hipStreamNonBlocking));
-    else HIP_TRY(ctx, hipExtStreamCreateWithCUMask(out, (uint32_t)ctx->cu_mask.size(), ctx->cu_mask.data()));
+// high_priority: the copy stream of the row-block pipeline.  A process has few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+// default) and HIP deals its streams to them per PRIORITY level: in a process with many streams a normal-priority copy
+// stream can land on the queue of one of the pipeline's own compute streams, and its copies then wait behind that
+// stream's kernels again (measured: config E's host step 2.90 -> 3.01 ms inside bench.py, where the main context's
+// streams are alive next to the leg's).  A high-priority stream takes its queue from another pool.
+int create_stream(mcalf_ctx* ctx, hipStream_t* out, bool high_priority) {
+    if (!ctx->cu_mask.empty()) {
+        HIP_TRY(ctx, hipExtStreamCreateWithCUMask(out, (uint32_t)ctx->cu_mask.size(), ctx->cu_mask.data()));
+    } else if (high_priority) {
+        int least = 0, greatest = 0;
+        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(ctx, hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest));
+    } else {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    }
     return MCALF_OK;
 }
 
@@ -588,11 +600,12 @@ static int pick_chunks(const mcalf_ctx* ctx, int64_t batch) {
     return n < 1 ? 1 : n;
 }
 
-static int ensure_aux(mcalf_ctx* ctx, int naux) {
+constexpr int kCopyStream = 1;          // aux[1]: the copy stream of the row-block pipeline (when that path created it)
+static int ensure_aux(mcalf_ctx* ctx, int naux, bool copy_stream = false) {
     if (!ctx->ev_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < naux; ++i) {
         if (!ctx->aux[i]) {
-            const int rc = create_stream(ctx, &ctx->aux[i]);
+            const int rc = create_stream(ctx, &ctx->aux[i], i == kCopyStream && copy_stream);
             if (rc) return rc;
         }
         if (!ctx->ev_join[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
@@ -908,7 +921,7 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
     int64_t bounds[kMaxChunks + 1];
     int nchunks = plan_row_blocks(ctx, batch, rowlen, pin_in, bounds);
     if (ctx->profiling) { nchunks = 1; bounds[1] = batch; }
-    if ((rc = ensure_aux(ctx, 2))) return rc;
+    if ((rc = ensure_aux(ctx, 2, true))) return rc;
     for (hipEvent_t& e : ctx->ev_h2d)
         if (!e) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const bool reduces = (mode == kModeLogL || mode == kModeChi2);
@@ -923,7 +936,7 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
         ctx->cap_stage = need;
     }
     double* stage_in = pin_in ? nullptr : ctx->h_stage;
-    hipStream_t copy_stream = ctx->aux[1];
+    hipStream_t copy_stream = ctx->aux[kCopyStream];
     double* stage_out = pin_out ? out_scalar : ctx->h_stage + (pin_in ? 0 : (size_t)batch * rowlen);
     // Results: the kernels write logL straight into the page-locked block (its device address), 8 bytes per live
     // point over PCIe, which saves the D2H copy command of every block -- the last one is on the critical path.
