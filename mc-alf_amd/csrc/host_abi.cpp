@@ -372,21 +372,24 @@ extern "C" int mcalf_last_launch(const mcalf_ctx* ctx, mcalf_launch_info_t* info
 }
 
 // A stream of the context: non-blocking, or -- with a CU mask (mcalf_set_cu_mask) -- restricted to the mask's CUs.
-// high_priority: the copy stream of the row-block pipeline.  A process has few hardware queues (GPU_MAX_HW_QUEUES, 4 by
-// default) and HIP deals its streams to them per PRIORITY level: in a process with many streams a normal-priority copy
-// stream can land on the queue of one of the pipeline's own compute streams, and its copies then wait behind that
-// stream's kernels again (measured: config E's host step 2.90 -> 3.01 ms inside bench.py, where the main context's
-// streams are alive next to the leg's).  A high-priority stream takes its queue from another pool.
-int create_stream(mcalf_ctx* ctx, hipStream_t* out, bool high_priority) {
+// priority: +1 the copy stream, -1 the second compute stream of the row-block pipeline, 0 everything else.  A process has
+// few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and HIP deals its streams to them per PRIORITY level: in a process
+// with many streams (an application with several contexts; bench.py's legs next to its main context) two of the pipeline's
+// three streams can land on ONE queue -- its row blocks then run strictly one after the other (measured with
+// MCALF_HOST_TRACE=2: config E's host step 2.90 -> 2.99 ms), or its copies wait behind kernels again.  Streams of different
+// priority levels take their queues from different pools, so the three never share.
+int create_stream(mcalf_ctx* ctx, hipStream_t* out, int priority) {
     if (!ctx->cu_mask.empty()) {
         HIP_TRY(ctx, hipExtStreamCreateWithCUMask(out, (uint32_t)ctx->cu_mask.size(), ctx->cu_mask.data()));
-    } else if (high_priority) {
-        int least = 0, greatest = 0;
-        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_TRY(ctx, hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest));
-    } else {
-        HIP_TRY(ctx, hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+        return MCALF_OK;
     }
+    int least = 0, greatest = 0;
+    if (priority != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+        HIP_TRY(ctx, hipStreamCreateWithPriority(out, hipStreamNonBlocking, priority > 0 ? greatest : least));
+        return MCALF_OK;
+    }
+    (void)hipGetLastError();
+    HIP_TRY(ctx, hipStreamCreateWithFlags(out, hipStreamNonBlocking));
     return MCALF_OK;
 }
 
@@ -600,12 +603,12 @@ static int pick_chunks(const mcalf_ctx* ctx, int64_t batch) {
     return n < 1 ? 1 : n;
 }
 
-constexpr int kCopyStream = 1;          // aux[1]: the copy stream of the row-block pipeline (when that path created it)
-static int ensure_aux(mcalf_ctx* ctx, int naux, bool copy_stream = false) {
+constexpr int kCopyStream = 1;          // aux[1]: the copy stream of the row-block pipeline; aux[0]: its second compute stream
+static int ensure_aux(mcalf_ctx* ctx, int naux, bool pipeline = false) {
     if (!ctx->ev_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < naux; ++i) {
         if (!ctx->aux[i]) {
-            const int rc = create_stream(ctx, &ctx->aux[i], i == kCopyStream && copy_stream);
+            const int rc = create_stream(ctx, &ctx->aux[i], !pipeline ? 0 : (i == kCopyStream ? +1 : -1));
             if (rc) return rc;
         }
         if (!ctx->ev_join[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));

@@ -303,7 +303,7 @@ int launch_finalize(mcalf_ctx* ctx, const KArgs& a, int64_t nrows, int mode, hip
 int ensure_small(mcalf_ctx* ctx);                      // the page-locked block of small calls
 bool is_pinned_host(const void* p);
 // A stream of the context: created with the context's CU mask when it has one (mcalf_set_cu_mask).
-int create_stream(mcalf_ctx* ctx, hipStream_t* out, bool high_priority = false);
+int create_stream(mcalf_ctx* ctx, hipStream_t* out, int priority = 0);
 
 void apply_environment(mcalf_ctx* ctx);                // host_config.cpp: the environment's snapshot over the built-in values
 // Entries that make no sense on a multi-device parent (device pointers belong to ONE device; a communicator, a resident
