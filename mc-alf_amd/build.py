@@ -1,7 +1,7 @@
 """Build libmcalf_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-The library is five translation units: kernels.hip (every kernel: the only file compiled for the device) and the host
-side of the C ABI -- host_abi.cpp, host_stream.cpp, broker.cpp, comm.cpp -- compiled as plain C++ against the HIP
+The library is seven translation units: kernels.hip (every kernel: the only file compiled for the device) and the host
+side of the C ABI -- host_abi.cpp, host_stream.cpp, host_config.cpp, host_multi.cpp, broker.cpp, comm.cpp -- compiled as plain C++ against the HIP
 runtime API.  Objects are kept under csrc/obj/ so that an edit of a host file does not recompile the kernels (22 s)."""
 from __future__ import annotations
 
