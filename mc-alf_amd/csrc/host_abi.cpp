@@ -810,19 +810,12 @@ bool is_pinned_host(const void* p) {
     return at.type == hipMemoryTypeHost;
 }
 
-// MCALF_HOST_TRACE=1 (diagnostic): where a call of the row-block pipeline spends its host time, printed when the context
-// is destroyed (mean microseconds per call): staging copies by the calling thread (and the rate they ran at), copies its
-// helper took over, enqueueing (H2D commands + launches), the wait for the streams, the copy of the results.
+// MCALF_HOST_TRACE=1 (diagnostic; accumulators in the context: host_ctx.h): where a call of the row-block pipeline spends its host
+// time, printed when the context is destroyed (mean microseconds per call): staging copies by the calling thread (and the rate they
+// ran at), copies its helpers took over, enqueueing split by API call, the wait for the streams, the copy of the results.
+// MCALF_HOST_TRACE=2: additionally the GPU-side timeline of the LAST pipelined call -- per row block the times (us after the call
+// began) at which its H2D copy started and ended and its kernels ended on the device, and when the host enqueued it.
 namespace {
-struct HostTrace { double stage_us = 0, stage_bytes = 0, helper_bytes = 0, helper_wait_us = 0, enqueue_us = 0, wait_us = 0, out_us = 0, first_enqueued_us = 0;
-                   double call_copy_us = 0, call_order_us = 0, call_launch_us = 0, call_copy_max = 0; long calls = 0, blocks = 0;
-                   double small_prep_us = 0, small_launch_us = 0, small_copy_us = 0, small_poll_us = 0, small_out_us = 0; long small_calls = 0; };
-HostTrace g_host_trace;
-// MCALF_HOST_TRACE=2: additionally the GPU-side timeline of the LAST pipelined call -- per row block the times (us after the
-// call began) at which its H2D copy started and ended and its kernels ended on the device, and when the host enqueued it
-struct BlockTimeline { int n = 0; long rows[kMaxChunks]; float h2d0[kMaxChunks], h2d1[kMaxChunks], done[kMaxChunks]; double host_enq[kMaxChunks], call_h2d[kMaxChunks], call_order[kMaxChunks], call_launch[kMaxChunks]; int pinned = 0; double sync_us = 0; };
-BlockTimeline g_block_timeline;
-
 // The staging copy of one call, shared between the calling thread (blocks from the front, in the order the GPU wants
 // them) and the helper threads (blocks from the back): whoever claims a block copies it; `copied` says it is there.
 struct StageJob {
@@ -846,17 +839,17 @@ int stage_from_back(void*, int64_t, int64_t, void* arg) {
 }
 }  // namespace
 
-void host_trace_report(const mcalf_ctx* ctx) {
-    if (ctx->host_trace && g_host_trace.small_calls > 0) {
-        const HostTrace& t = g_host_trace;
+void host_trace_report(mcalf_ctx* ctx) {
+    if (ctx->host_trace && ctx->htrace.small_calls > 0) {
+        const HostTrace& t = ctx->htrace;
         const double n = (double)t.small_calls;
         std::fprintf(stderr, "mcalf host trace (zero-copy small calls, %ld calls; us per call): copy into the page-locked block %.2f, launch calls %.2f, "
                      "theta rows on the host %.2f, wait for the results %.2f, results out %.2f\n", t.small_calls,
                      t.small_prep_us / n, t.small_launch_us / n, t.small_copy_us / n, t.small_poll_us / n, t.small_out_us / n);
-        if (g_host_trace.calls == 0) g_host_trace = HostTrace();
+        if (ctx->htrace.calls == 0) ctx->htrace = HostTrace();
     }
-    if (!ctx->host_trace || g_host_trace.calls == 0) return;
-    const HostTrace& t = g_host_trace;
+    if (!ctx->host_trace || ctx->htrace.calls == 0) return;
+    const HostTrace& t = ctx->htrace;
     const double n = (double)t.calls;
     std::fprintf(stderr, "mcalf host trace (row-block pipeline, %ld calls, %.1f blocks per call; us per call): staging copy by the caller %.1f "
                  "(%.2f GB/s), by helpers %.0f KB (waited %.1f), first block enqueued at %.1f, enqueue %.1f (of it: hipMemcpyAsync calls %.1f [longest single "
@@ -864,14 +857,14 @@ void host_trace_report(const mcalf_ctx* ctx) {
                  "results out %.1f\n", t.calls, (double)t.blocks / n, t.stage_us / n, t.stage_us > 0 ? t.stage_bytes / t.stage_us * 1e-3 : 0.0,
                  t.helper_bytes / n / 1024.0, t.helper_wait_us / n, t.first_enqueued_us / n, t.enqueue_us / n, t.call_copy_us / n, t.call_copy_max,
                  t.call_order_us / n, t.call_launch_us / n, t.wait_us / n, t.out_us / n);
-    g_host_trace = HostTrace();
-    const BlockTimeline& b = g_block_timeline;
+    ctx->htrace = HostTrace();
+    const BlockTimeline& b = ctx->btrace;
     for (int c = 0; c < b.n; ++c)
         std::fprintf(stderr, "mcalf host trace, last call (%s rows), block %d: %ld rows, enqueued by the host at %.1f us (calls: copy %.1f, ordering %.1f, launches %.1f); "
                      "on the device: H2D %.1f .. %.1f, kernels done %.1f\n", b.pinned ? "page-locked" : "pageable", c, b.rows[c], b.host_enq[c], b.call_h2d[c], b.call_order[c],
                      b.call_launch[c], b.h2d0[c] * 1e3, b.h2d1[c] * 1e3, b.done[c] * 1e3);
     if (b.n) std::fprintf(stderr, "mcalf host trace, last call: the stream waits returned %.1f us after the call began\n", b.sync_us);
-    g_block_timeline = BlockTimeline();
+    ctx->btrace = BlockTimeline();
 }
 
 // The row blocks of a pipelined host-pointer call.  The FIRST block is sized by BYTES (ctx->host_first_kb KiB of
@@ -979,8 +972,8 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
     if (timeline) {
         for (hipEvent_t& e : tev) (void)hipEventCreate(&e);
         (void)hipEventRecord(tev[3 * kMaxChunks], ctx->stream);
-        g_block_timeline = BlockTimeline();
-        g_block_timeline.pinned = pin_in ? 1 : 0;
+        ctx->btrace = BlockTimeline();
+        ctx->btrace.pinned = pin_in ? 1 : 0;
     }
     for (int c = 0; c < nchunks && rc == MCALF_OK && he == hipSuccess; ++c) {
         const int64_t r0 = bounds[c], n = bounds[c + 1] - r0;
@@ -1020,11 +1013,11 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
         }
         if (trace) {
             const double tc3 = now_us();
-            g_host_trace.call_copy_us += tc1 - tc0; g_host_trace.call_order_us += tc2 - tc1; g_host_trace.call_launch_us += tc3 - tc2;
-            g_host_trace.call_copy_max = std::max(g_host_trace.call_copy_max, tc1 - tc0);
-            if (timeline) { g_block_timeline.call_h2d[c] = tc1 - tc0; g_block_timeline.call_order[c] = tc2 - tc1; g_block_timeline.call_launch[c] = tc3 - tc2; }
+            ctx->htrace.call_copy_us += tc1 - tc0; ctx->htrace.call_order_us += tc2 - tc1; ctx->htrace.call_launch_us += tc3 - tc2;
+            ctx->htrace.call_copy_max = std::max(ctx->htrace.call_copy_max, tc1 - tc0);
+            if (timeline) { ctx->btrace.call_h2d[c] = tc1 - tc0; ctx->btrace.call_order[c] = tc2 - tc1; ctx->btrace.call_launch[c] = tc3 - tc2; }
         }
-        if (timeline) { (void)hipEventRecord(tev[3 * c + 2], st); g_block_timeline.rows[c] = (long)n; g_block_timeline.host_enq[c] = now_us() - t_begin; g_block_timeline.n = c + 1; }
+        if (timeline) { (void)hipEventRecord(tev[3 * c + 2], st); ctx->btrace.rows[c] = (long)n; ctx->btrace.host_enq[c] = now_us() - t_begin; ctx->btrace.n = c + 1; }
         if (trace) { const double t2 = now_us(); t_enq += t2 - t1; if (c == 0) t_first = t2 - t_begin; }
     }
     for (int h = 0; h < helpers; ++h) (void)ctx->stagers[h]->wait();      // (the job lives on this frame)
@@ -1038,17 +1031,17 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
         return set_err(ctx, MCALF_ERR_HIP, "stream synchronisation failed: %s", hipGetErrorString(s0 != hipSuccess ? s0 : s1));
     const double t_w1 = trace ? now_us() : 0.0;
     if (timeline) {
-        g_block_timeline.sync_us = t_w1 - t_begin;
-        for (int c = 0; c < g_block_timeline.n; ++c) {
-            (void)hipEventElapsedTime(&g_block_timeline.h2d0[c], tev[3 * kMaxChunks], tev[3 * c]);
-            (void)hipEventElapsedTime(&g_block_timeline.h2d1[c], tev[3 * kMaxChunks], tev[3 * c + 1]);
-            (void)hipEventElapsedTime(&g_block_timeline.done[c], tev[3 * kMaxChunks], tev[3 * c + 2]);
+        ctx->btrace.sync_us = t_w1 - t_begin;
+        for (int c = 0; c < ctx->btrace.n; ++c) {
+            (void)hipEventElapsedTime(&ctx->btrace.h2d0[c], tev[3 * kMaxChunks], tev[3 * c]);
+            (void)hipEventElapsedTime(&ctx->btrace.h2d1[c], tev[3 * kMaxChunks], tev[3 * c + 1]);
+            (void)hipEventElapsedTime(&ctx->btrace.done[c], tev[3 * kMaxChunks], tev[3 * c + 2]);
         }
         for (hipEvent_t e : tev) if (e) (void)hipEventDestroy(e);
     }
     if (!pin_out) std::memcpy(out_scalar, stage_out, (size_t)batch * sizeof(double));
     if (trace) {
-        HostTrace& t = g_host_trace;
+        HostTrace& t = ctx->htrace;
         t.calls++; t.blocks += nchunks; t.stage_us += t_stage; t.stage_bytes += stage_bytes; t.helper_wait_us += t_hwait;
         t.helper_bytes += helpers ? (double)job.helper_bytes.load() : 0.0; t.enqueue_us += t_enq; t.first_enqueued_us += t_first;
         t.wait_us += t_w1 - t_w0; t.out_us += now_us() - t_w1;
@@ -1108,7 +1101,7 @@ static int run_host_small(mcalf_ctx* ctx, int mode, const double* P, int64_t bat
     const double ts4 = trace ? now_us() : 0.0;
     std::memcpy(out_scalar, ctx->h_small + kSmallDoubles, (size_t)batch * sizeof(double));
     if (trace) {
-        HostTrace& t = g_host_trace;
+        HostTrace& t = ctx->htrace;
         t.small_calls++; t.small_prep_us += ts1 - ts0; t.small_launch_us += ts2 - ts1; t.small_copy_us += ts3 - ts2;
         t.small_poll_us += ts4 - ts3; t.small_out_us += now_us() - ts4;
     }

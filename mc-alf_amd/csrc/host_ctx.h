@@ -127,7 +127,18 @@ struct EnvKnobs {
 };
 EnvKnobs read_environment();                // host_config.cpp
 
+// Diagnostics (MCALF_HOST_TRACE / MCALF_STREAM_TRACE): accumulators of ONE context (a context is not re-entrant, so they need no
+// lock; the entries of a multi-device context each keep and print their own), printed when the context is destroyed.
+struct HostTrace { double stage_us = 0, stage_bytes = 0, helper_bytes = 0, helper_wait_us = 0, enqueue_us = 0, wait_us = 0, out_us = 0, first_enqueued_us = 0;
+                   double call_copy_us = 0, call_order_us = 0, call_launch_us = 0, call_copy_max = 0; long calls = 0, blocks = 0;
+                   double small_prep_us = 0, small_launch_us = 0, small_copy_us = 0, small_poll_us = 0, small_out_us = 0; long small_calls = 0; };
+struct BlockTimeline { int n = 0; long rows[kMaxChunks]; float h2d0[kMaxChunks], h2d1[kMaxChunks], done[kMaxChunks]; double host_enq[kMaxChunks], call_h2d[kMaxChunks], call_order[kMaxChunks], call_launch[kMaxChunks]; int pinned = 0; double sync_us = 0; };
+struct StreamTrace { double t[6] = {}; long n = 0; };
+
 struct mcalf_ctx {
+    HostTrace htrace;
+    BlockTimeline btrace;
+    StreamTrace strace;
     EnvKnobs env;                           // what the environment said when the context was created
     int device = 0;
     std::string arch;
@@ -333,8 +344,8 @@ bool stream_qualifies(const mcalf_ctx* ctx, int64_t batch);
 void host_scale_cube(const mcalf_ctx* ctx, const double* cube, int64_t batch, double* theta);
 int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, int rowlen, double* out_scalar, bool* taken,
                     bool from_cube = false, double* theta_out = nullptr);
-void stream_trace_report(const mcalf_ctx* ctx);
-void host_trace_report(const mcalf_ctx* ctx);          // host_abi.cpp: MCALF_HOST_TRACE, the row-block pipeline's phases
+void stream_trace_report(mcalf_ctx* ctx);
+void host_trace_report(mcalf_ctx* ctx);          // host_abi.cpp: MCALF_HOST_TRACE, the row-block pipeline's phases
 
 // ---- broker.cpp: resident one-theta evaluator ---------------------------------------------------------------------------
 void resident_stop(mcalf_ctx* ctx);

@@ -2,21 +2,17 @@
 // mcalf_fused_kernel<..., kStream = true>).
 #include "host_ctx.h"
 
-namespace {
-// MCALF_STREAM_TRACE=1 (diagnostic): mean host-side microseconds per phase of the streaming entry, printed when the
+// MCALF_STREAM_TRACE=1 (diagnostic): mean host-side microseconds per phase of the streaming entry (ctx->strace), printed when the
 // context is destroyed
-struct StreamTrace { double t[6] = {}; long n = 0; };
-StreamTrace g_stream_trace;
-}  // namespace
 
-void stream_trace_report(const mcalf_ctx* ctx) {
-    if (!ctx->stream_trace || g_stream_trace.n == 0) return;
-    const double n = (double)g_stream_trace.n;
+void stream_trace_report(mcalf_ctx* ctx) {
+    if (!ctx->stream_trace || ctx->strace.n == 0) return;
+    const double n = (double)ctx->strace.n;
     std::fprintf(stderr, "mcalf stream trace (%ld calls, us per call; workgroups per XCD in the last launch: %u .. %u): pointer checks %.2f, "
-                 "prepare %.2f, launch %.2f, stage rows %.2f, wait %.2f, copy out %.2f\n", g_stream_trace.n,
-                 ctx->h_ctl ? ctx->h_ctl[2] : 0u, ctx->h_ctl ? ctx->h_ctl[3] : 0u, g_stream_trace.t[0] / n, g_stream_trace.t[1] / n, g_stream_trace.t[2] / n,
-                 g_stream_trace.t[3] / n, g_stream_trace.t[4] / n, g_stream_trace.t[5] / n);
-    g_stream_trace = StreamTrace();
+                 "prepare %.2f, launch %.2f, stage rows %.2f, wait %.2f, copy out %.2f\n", ctx->strace.n,
+                 ctx->h_ctl ? ctx->h_ctl[2] : 0u, ctx->h_ctl ? ctx->h_ctl[3] : 0u, ctx->strace.t[0] / n, ctx->strace.t[1] / n, ctx->strace.t[2] / n,
+                 ctx->strace.t[3] / n, ctx->strace.t[4] / n, ctx->strace.t[5] / n);
+    ctx->strace = StreamTrace();
 }
 
 // Workspaces of the streaming launch for `batch` live points, and the words it shares with the host.
@@ -322,8 +318,8 @@ int run_host_stream(mcalf_ctx* ctx, int mode, const double* P, int64_t batch, in
     if (!pin_out) std::memcpy(out_scalar, stage_out, (size_t)batch * sizeof(double));
     if (trace) {
         tm[6] = now_us();
-        for (int k = 0; k < 6; ++k) g_stream_trace.t[k] += tm[k + 1] - tm[k];
-        g_stream_trace.n++;
+        for (int k = 0; k < 6; ++k) ctx->strace.t[k] += tm[k + 1] - tm[k];
+        ctx->strace.n++;
     }
     *taken = true;
     return MCALF_OK;
