@@ -46,11 +46,11 @@
  * asynchronous call of a context on the same stream); distinct contexts are independent.
  * A resolution beyond the provisioned specres_max makes a row's model NaN, its logL -inf and
  * its chi2 +inf (the reference would allocate a longer kernel).  The provisioned LSF itself may be of
- * ANY width under MCALF_CONV_WRAP_NUMPY: one whose halo does not fit a 4096-pixel workgroup tile is
- * convolved from HBM by a second pair of kernels behind the fused one (same entries, same values;
- * hires_fitter.py:458-464).  MCALF_CONV_SAME_EDGE_JAX keeps its fixed kernel grid inside a tile
- * (MCALF_ERR_RANGE beyond it; MCALF_ERR_INVALID for a grid longer than the spectrum, which the
- * reference's jnp.convolve / jnp.where cannot broadcast either).
+ * ANY width, under both boundary modes: one whose halo does not fit a 4096-pixel workgroup tile is
+ * convolved by a second pair of kernels behind the fused one (same entries, same conventions;
+ * hires_fitter.py:458-464 / the fixed grid of :549-560).  Only a MCALF_CONV_SAME_EDGE_JAX grid longer than
+ * the spectrum is refused (MCALF_ERR_INVALID): the reference's jnp.convolve / jnp.where cannot broadcast
+ * it either.
  */
 #ifndef MCALF_HIP_H
 #define MCALF_HIP_H

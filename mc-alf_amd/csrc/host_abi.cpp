@@ -164,10 +164,10 @@ static int create_impl(const mcalf_spec* sp, mcalf_ctx* ctx) {
     ctx->lps = ((ctx->ncl_cap + 4) / 5 < (ctx->ncl_cap + 3) / 4 && ext_for(5) == ext_for(4)) ? 5 : 4;
     if (ctx->env.lines_per_sync == 4 || (ctx->env.lines_per_sync == 5 && ext_for(5) == ext_for(4))) ctx->lps = ctx->env.lines_per_sync;
     if (ext_for(ctx->lps) < 2 * (size_t)ctx->n_cap + 64) {
-        // The LSF does not fit a workgroup tile with its halo.  numpy boundary: the fused kernel then runs without
-        // convolution (a tile without halo) and the wide kernels convolve from HBM (launch_wide) -- the reference simply
-        // builds a longer kernel (hires_fitter.py:458-464).  JAX semantics keep their fixed grid inside the tile.
-        if (ctx->conv_mode != MCALF_CONV_WRAP_NUMPY || 2.0 * (double)ctx->n_cap + 1.0 > 6.0e7)
+        // The LSF does not fit a workgroup tile with its halo: the fused kernel then runs without convolution (a tile
+        // without halo) and the wide kernels convolve behind it (launch_wide) -- the reference simply builds a longer
+        // kernel (hires_fitter.py:458-464; JAX semantics: its fixed grid, :549-560, whatever its length).
+        if (2.0 * (double)ctx->n_cap + 1.0 > 6.0e7)
             return set_err(ctx, MCALF_ERR_RANGE,
                            "LSF half-width %d px (specres_max %.3g km/s at %.3g km/s/px) with %d component-lines does not "
                            "fit a %d-pixel workgroup tile / the %zu-byte LDS budget", ctx->n_cap, rmax, sp->velstep,
@@ -518,7 +518,10 @@ KArgs make_kargs(const mcalf_ctx* ctx, int mode, const double* dP, int64_t row0,
     if (wide_stage == kWideFused) {
         // the convolution-free fused launch of a wide-LSF context: no resolution exceeds this step (hires_fitter.py:445), the
         // continuum is 1 -- the wide kernels apply both afterwards (the layout fields startind / endind stay the context's)
-        a.velstep = 1e300; a.freecont = 0; a.contval_fixed = 1.0;
+        // (JAX semantics convolve unconditionally on their fixed grid: a grid of half-width 0 -- the single tap 1 -- is the
+        // identity, and its edge reset covers no pixel; velstep stays, sigma must remain finite there)
+        a.freecont = 0; a.contval_fixed = 1.0;
+        if (ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX) a.jax_half = 0; else a.velstep = 1e300;
     } else if (wide_stage == kWideKernels) {
         a.n_cap = ctx->wide_n_cap;                        // (arguments of the wide kernels)
     }
@@ -647,6 +650,7 @@ int launch_preflight(mcalf_ctx* ctx, int mode, int64_t batch) {
 static int launch_wide(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch, int targonly, int onecomp_fill, double* d_out,
                        double* d_model, hipStream_t stream, bool from_cube, double* d_theta) {
     const int64_t npix = ctx->npix, tapw = 2 * (int64_t)ctx->wide_n_cap + 1;
+    const bool jax = ctx->conv_mode == MCALF_CONV_SAME_EDGE_JAX;
     const int rowlen = (mode == kModeOneComp) ? 5 : ctx->ndim;
     const bool reduces = (mode == kModeLogL || mode == kModeChi2);
     const int64_t rows = wide_rows_per_pass(ctx, batch);
@@ -686,11 +690,11 @@ static int launch_wide(mcalf_ctx* ctx, int mode, const double* dP, int64_t batch
         int nb = nblocks;
         {
             void* kargs[] = {(void*)&a, (void*)&taps, (void*)&stride, (void*)&hdr};
-            HIP_TRY(ctx, hipLaunchKernel(wide_taps_kernel_ptr(), dim3((unsigned)n), dim3(kWideBlockThreads), kargs, 0, stream));
+            HIP_TRY(ctx, hipLaunchKernel(wide_taps_kernel_ptr(jax), dim3((unsigned)n), dim3(kWideBlockThreads), kargs, 0, stream));
         }
         {
             void* kargs[] = {(void*)&a, (void*)&flux, (void*)&taps_c, (void*)&stride, (void*)&hdr_c, (void*)&nb};
-            HIP_TRY(ctx, hipLaunchKernel(wide_conv_kernel_ptr(), dim3((unsigned)nblocks, (unsigned)n), dim3(kWideBlockThreads), kargs, 0, stream));
+            HIP_TRY(ctx, hipLaunchKernel(wide_conv_kernel_ptr(jax), dim3((unsigned)nblocks, (unsigned)n), dim3(kWideBlockThreads), kargs, 0, stream));
         }
         if (reduces && (rc = launch_finalize(ctx, a, n, mode, stream, nblocks))) return rc;   // (nblocks partials per live point)
     }

@@ -208,8 +208,8 @@ MCALF_INTERNAL const void* xcd_probe_kernel_ptr();             // (unsigned int*
 constexpr int kWideBlockThreads = 256;
 constexpr int kWideBlockPix = 8 * kWideBlockThreads;       // output pixels per workgroup of the wide convolution (eight per thread)
 constexpr int kWideTapChunk = 512;                         // taps staged in LDS per pass
-MCALF_INTERNAL const void* wide_taps_kernel_ptr();             // (const KArgs a, double* taps, long tap_stride, SampleHdr* hdr), grid = rows
-MCALF_INTERNAL const void* wide_conv_kernel_ptr();             // (const KArgs a, const double* flux, const double* taps, long tap_stride, const SampleHdr* hdr, int nblocks), grid = (ceil(npix / kWideBlockPix), rows)
+MCALF_INTERNAL const void* wide_taps_kernel_ptr(bool jax);             // (const KArgs a, double* taps, long tap_stride, SampleHdr* hdr), grid = rows
+MCALF_INTERNAL const void* wide_conv_kernel_ptr(bool jax);             // (const KArgs a, const double* flux, const double* taps, long tap_stride, const SampleHdr* hdr, int nblocks), grid = (ceil(npix / kWideBlockPix), rows)
 MCALF_INTERNAL const void* wide_rows_kernel_ptr();             // (const double* rows, double* out, long batch): (R, cont, N, z, b) rows with cont := 1
 
 }  // namespace mcalf

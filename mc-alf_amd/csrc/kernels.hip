@@ -1373,7 +1373,8 @@ __global__ void mcalf_scale_cube_kernel(const double* lo, const double* hi, cons
 // The fused kernel convolves inside a 4096-pixel LDS tile, halo included.  A context whose LSF half-width does not fit
 // one (a very finely sampled spectrum, a very coarse resolution: the reference simply builds a longer kernel,
 // hires_fitter.py:458-464) runs the SAME fused kernel without its convolution and continuum -- the host passes it
-// velstep = 1e300 (hires_fitter.py:445: no convolution while R <= velstep), a fixed continuum of 1 -- into a buffer of
+// velstep = 1e300 (hires_fitter.py:445: no convolution while R <= velstep; JAX semantics: a kernel grid of half-width 0,
+// i.e. the single tap 1), a fixed continuum of 1 -- into a buffer of
 // unconvolved spectra [rows][npix], and these two kernels do the rest: the taps of every live point (any half-width up
 // to the one provisioned from specres_max), then the periodic convolution, the continuum and the likelihood terms.
 // The convolution is the fused kernel's scheme at a larger scale: a workgroup owns kWideBlockPix consecutive outputs,
@@ -1409,6 +1410,9 @@ __device__ __forceinline__ void wide_decode(const KArgs& a, long s, double& R, d
 // One workgroup per live point: its normalised Gaussian taps w[0 .. 2n] (astropy's Gaussian1DKernel divided by its sum),
 // the sum `bot` astropy's loop divides by -- added up tap after tap, tap 0 first, the order the convolution's numerator
 // chain runs in (as setup_sample() does for the fused kernel) -- and the header (continuum, bot, n, bad).
+// kZeroPad (JAX semantics, hires_fitter.py:549-560,667-670): the kernel grid is FIXED at the context's half-width (from
+// the largest resolution), the taps are exp(-k^2 / 2 sigma^2) divided by their sum and nothing else divides (bot = 1).
+template <bool kZeroPad>
 __global__ __launch_bounds__(kWideBlock) void mcalf_wide_taps_kernel(const KArgs a, double* taps, long tap_stride, SampleHdr* hdr) {
     __shared__ double red[kWideBlock / 64];
     const long s = blockIdx.x;
@@ -1418,17 +1422,21 @@ __global__ __launch_bounds__(kWideBlock) void mcalf_wide_taps_kernel(const KArgs
     const double sigma = (R / kFwhmToSigma) / a.velstep;         // :454
     long n = 0;
     bool bad = false;
-    if (R > a.velstep) {                                         // :445
+    if (kZeroPad) {
+        n = a.jax_half;                                          // :549-560 fixed grid
+    } else if (R > a.velstep) {                                  // :445
         const double nd = ceil(kKernelReach * sigma);            // :458
         if (!(nd <= (double)a.n_cap)) bad = true;                // (beyond the half-width provisioned from specres_max; NaN too)
         else n = (long)nd;
     }
     double* w = taps + (size_t)s * tap_stride;
-    const double inv2s2 = 0.5 / (sigma * sigma), amp = 1.0 / (sqrt(2.0 * M_PI) * sigma);
+    // (the expressions of setup_sample(), so that a kernel that fits a tile and one that does not form their taps alike)
+    const double inv2s2 = kZeroPad ? 1.0 / (2.0 * sigma * sigma) : 0.5 / (sigma * sigma);
+    const double amp = kZeroPad ? 1.0 : 1.0 / (sqrt(2.0 * M_PI) * sigma);
     double part = 0.0;
     for (long k = tid; k <= 2 * n; k += kWideBlock) {
         const double dk = (double)(k - n);
-        const double g = (n == 0) ? 1.0 : exp_neg((dk * dk) * inv2s2) * amp;
+        const double g = (n == 0 && !kZeroPad) ? 1.0 : exp_neg((dk * dk) * inv2s2) * amp;
         w[k] = g;
         part += g;
     }
@@ -1438,7 +1446,8 @@ __global__ __launch_bounds__(kWideBlock) void mcalf_wide_taps_kernel(const KArgs
     __syncthreads();
     if (tid == 0) {
         double bot = 0.0;                                        // tap order: a dependent chain of 2n + 1 additions, once per live point
-        for (long k = 0; k <= 2 * n; ++k) bot += w[k];
+        if (kZeroPad) bot = 1.0;                                 // (:670 normalises the kernel; jnp.convolve divides by nothing)
+        else for (long k = 0; k <= 2 * n; ++k) bot += w[k];
         SampleHdr h;
         h.cont = cont; h.bot = bot; h.ncl = 0; h.n = (int)n; h.bad = bad ? 1 : 0; h.ngeneral = 0;
         hdr[s] = h;
@@ -1448,6 +1457,9 @@ __global__ __launch_bounds__(kWideBlock) void mcalf_wide_taps_kernel(const KArgs
 // Workgroup (blockIdx.x, blockIdx.y) = pixels [2048 x, 2048 x + 2048) of live point y:  model = (sum_k w_k flux[(i + k - n) mod
 // npix]) / bot x continuum (astropy boundary='wrap', taps in window order; hires_fitter.py:463-464, :447), then the model
 // row and / or the likelihood terms (:292-303) summed over the block into partial[y][x][4], which mcalf_finalize_kernel adds up.
+// kZeroPad (JAX semantics): jnp.convolve(model, kernel, 'same') -- zeros outside the spectrum instead of the periodic
+// window (:674) -- and the first / last n pixels reset to the unconvolved model (:677-681); nothing divides the sum.
+template <bool kZeroPad>
 __global__ __launch_bounds__(kWideBlock) void mcalf_wide_conv_kernel(const KArgs a, const double* flux, const double* taps, long tap_stride,
                                                                          const SampleHdr* hdr, int nblocks) {
     __shared__ double red[kWideBlock / 64];
@@ -1467,13 +1479,21 @@ __global__ __launch_bounds__(kWideBlock) void mcalf_wide_conv_kernel(const KArgs
         for (long k0 = 0; k0 < ntaps; k0 += kWideTapChunk) {
             const int kt = (int)min((long)kWideTapChunk, ntaps - k0);       // taps of this pass
             // window element e of the pass = flux[(i0 - n + k0 + e) mod npix]: output 8 t + m reads element 8 t + m + k at tap k0 + k
-            long src = (i0 - n + k0 + tid) % npix;
-            if (src < 0) src += npix;
-            const long step = kWideBlock % npix;
-            for (int e = tid; e < kWideBlockPix + kWideTapChunk + 16; e += kWideBlock) {
-                sF[wide_pos(e)] = (e < kWideBlockPix + kt) ? f[src] : 0.0;   // (past the pass's window: never multiplied by a tap)
-                src += step;
-                if (src >= npix) src -= npix;
+            if (kZeroPad) {
+                const long first = i0 - n + k0;
+                for (int e = tid; e < kWideBlockPix + kWideTapChunk + 16; e += kWideBlock) {
+                    const long j = first + e;
+                    sF[wide_pos(e)] = (e < kWideBlockPix + kt && j >= 0 && j < npix) ? f[j] : 0.0;      // :674 zero padding
+                }
+            } else {
+                long src = (i0 - n + k0 + tid) % npix;
+                if (src < 0) src += npix;
+                const long step = kWideBlock % npix;
+                for (int e = tid; e < kWideBlockPix + kWideTapChunk + 16; e += kWideBlock) {
+                    sF[wide_pos(e)] = (e < kWideBlockPix + kt) ? f[src] : 0.0;   // (past the pass's window: never multiplied by a tap)
+                    src += step;
+                    if (src >= npix) src -= npix;
+                }
             }
             for (int k = tid; k < kWideTapChunk; k += kWideBlock) sW[k] = (k < kt) ? w[k0 + k] : 0.0;
             __syncthreads();
@@ -1516,8 +1536,9 @@ __global__ __launch_bounds__(kWideBlock) void mcalf_wide_conv_kernel(const KArgs
         if (i >= npix) break;
         double mval = NAN;
         if (!h.bad) {
-            mval = top[m] / h.bot;
-            mval *= h.cont;                                      // :447
+            mval = kZeroPad ? top[m] : top[m] / h.bot;
+            if (kZeroPad && (i < n || i >= npix - n)) mval = f[i];       // :677-681 edge reset to the unconvolved model
+            mval *= h.cont;                                      // :447 / :683
         }
         if (a.model) a.model[(size_t)s * npix + i] = mval;
         if (reduces) {
@@ -1588,8 +1609,12 @@ const void* finalize_kernel_ptr() { return reinterpret_cast<const void*>(&mcalf_
 const void* hjert_kernel_ptr() { return reinterpret_cast<const void*>(&mcalf_hjert_kernel); }
 const void* scale_cube_kernel_ptr() { return reinterpret_cast<const void*>(&mcalf_scale_cube_kernel); }
 const void* xcd_probe_kernel_ptr() { return reinterpret_cast<const void*>(&mcalf_xcd_probe_kernel); }
-const void* wide_taps_kernel_ptr() { return reinterpret_cast<const void*>(&mcalf_wide_taps_kernel); }
-const void* wide_conv_kernel_ptr() { return reinterpret_cast<const void*>(&mcalf_wide_conv_kernel); }
+const void* wide_taps_kernel_ptr(bool jax) {
+    return jax ? reinterpret_cast<const void*>(&mcalf_wide_taps_kernel<true>) : reinterpret_cast<const void*>(&mcalf_wide_taps_kernel<false>);
+}
+const void* wide_conv_kernel_ptr(bool jax) {
+    return jax ? reinterpret_cast<const void*>(&mcalf_wide_conv_kernel<true>) : reinterpret_cast<const void*>(&mcalf_wide_conv_kernel<false>);
+}
 const void* wide_rows_kernel_ptr() { return reinterpret_cast<const void*>(&mcalf_wide_rows_kernel); }
 
 }  // namespace mcalf

@@ -125,9 +125,46 @@ def test_wide_lsf_resolution_beyond_the_provisioned_maximum_and_no_convolution()
         assert np.abs(m[2] - o.reconstruct_spec(prob, P[2])).max() < 1e-11
 
 
-def test_jax_semantics_keep_their_fixed_grid_inside_the_tile():
+@pytest.mark.parametrize("npix,velstep,specres,contval,nfill", [
+    (6000, 0.0045, (8.0,), (1.0,), 0),             # fixed grid of 2 x 2292 + 1 taps on two pixel tiles
+    (5200, 0.0045, (7.0, 8.0), (0.9, 1.1), 1),     # free resolution (grid from specres[1], hires_fitter.py:549-550), free continuum, a filler
+])
+def test_wide_lsf_under_jax_semantics(npix, velstep, specres, contval, nfill):
+    """Round 6: the JAX path's fixed kernel grid (hires_fitter.py:549-560, 667-681) may be wider than a workgroup tile too:
+    the fused kernel runs with a grid of half-width 0 (the single tap 1) and the wide kernels do the zero-padded 'same'
+    convolution, the reset of the first / last n pixels to the unconvolved model and the continuum.  Against the oracle's
+    float64 restatement of that path; device entry == host entry."""
+    kw = dict(_problem(npix, velstep, specres, contval, nfill, seed=npix), conv_mode="jax")
+    prob = problem_from_kwargs(kw)
+    P = workloads.draw_P(kw, 5, np.random.default_rng(3 + npix))
+    with mcalf_amd.als_fitter(None, **kw) as fit:
+        n = o.jax_half_size(prob)
+        assert fit.info.n_cap == n and 2 * n + 64 > 4096 and 2 * n + 1 <= npix
+        got = fit.loglike_batch(P)
+        want = np.array([o.jax_loglike_f64(prob, p) for p in P])
+        assert np.all(np.abs(got - want) < 1e-10 * np.abs(want) + 1e-9), (got, want)
+        m = fit.model_batch(P[:2])
+        for a, p in zip(m, P[:2]):
+            ref = o.jax_reconstruct_spec_f64(prob, p)
+            assert np.abs(a - ref).max() < 1e-11
+            assert np.array_equal(a[:3], ref[:3]) or np.abs(a[:3] - ref[:3]).max() < 1e-13      # (edge pixels: the unconvolved model)
+        dP = torch.from_numpy(P).cuda()
+        out = torch.full((len(P),), float("nan"), dtype=torch.float64, device="cuda")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(fit._lib.mcalf_loglike_batch_device(fit._ctx, dP.data_ptr(), len(P), out.data_ptr(), st), fit._ctx)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), got)
+        big = workloads.draw_P(kw, 600, np.random.default_rng(5))
+        big[:5] = P
+        assert np.array_equal(fit.loglike_batch(big)[:5], got)
+        assert fit.get_jax_likelihood(use_jax=False)(P[0].astype(np.float32)).dtype == np.float32
+
+
+def test_jax_grid_longer_than_the_spectrum_is_refused():
+    """A JAX-semantics kernel grid LONGER than the spectrum stays an error (MCALF_ERR_INVALID): the reference's
+    jnp.convolve(..., 'same') / jnp.where (hires_fitter.py:674-681) cannot broadcast it either."""
     kw = _problem(1500, 0.004, (8.0,), (1.0,), 0, seed=1)
-    with pytest.raises(RuntimeError, match="MCALF_ERR_RANGE|MCALF_ERR_INVALID"):
+    with pytest.raises(RuntimeError, match="MCALF_ERR_INVALID"):
         mcalf_amd.als_fitter(None, conv_mode="jax", **kw)
 
 
