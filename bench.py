@@ -270,6 +270,56 @@ def config_leg(config, rows=None, steps=20, device=0, parity_rows=64):
                 "parity": {"rows": int(idx.size), "max_abs_dlogL_vs_oracle": float(np.abs(logl_dev[idx] - want).max())}}
 
 
+def multi_device_leg(devices, steps=10):
+    """ONE process, several GPUs (mcalf_create_multi): BASELINE config D's 32768 rows through the host-pointer entry of a
+    context over `devices` (contiguous row blocks, one per device, no collective) against the same call on the first device
+    alone.  Runs in a child process of `bench.py` (see `run_multi_device_leg`), on nodes where this process sees several GPUs."""
+    kw, batch, seed = workloads.config("D", hip_synth)
+    P = np.ascontiguousarray(workloads.draw_P(kw, batch, np.random.default_rng(seed)))
+    sync = torch.cuda.synchronize
+    res = {"workload": WORKLOAD_LABEL["D"] + ", all rows in ONE process", "rows": batch, "devices": list(devices), "steps": steps,
+           "entry": "mcalf_loglike_batch (pageable numpy arrays in, logL out inside every step)"}
+    ref = None
+    for n in sorted({1, 2, 4, len(devices)}):
+        if n > len(devices):
+            continue
+        use = list(devices[:n])
+        with mcalf_amd.als_fitter(None, device=use if n > 1 else use[0], **kw) as fit:
+            out = np.empty(batch)
+            for _ in range(3):
+                fit.loglike_batch(P, out=out)
+            ms = median_pass_ms(lambda: fit.loglike_batch(P, out=out), steps, sync)
+            if ref is None:
+                ref = (ms, out.copy())
+            nc = P[:, fit.startind].astype(int)
+            res["n%d" % n] = {"devices": use, "ms_per_step": ms, "value": float(nc.sum()) * fit.obj_wl.size / (ms * 1e-3),
+                              "speedup_vs_one_device": ref[0] / ms, "devices_used": int(fit.last_launch().devices_used),
+                              "bit_equal_to_one_device": bool(np.array_equal(out, ref[1]))}
+    return res
+
+
+def run_multi_device_leg(timeout_s=240.0):
+    """The leg above in a CHILD process with a time limit (a fresh process: a hang or a fault on hardware this path has never
+    met must not take the bench line with it).  None when this process sees one GPU (MCALF_BENCH_MULTI_DEVICES=0,0 forces a
+    device list -- entries may repeat -- for a plumbing check on a one-GPU box)."""
+    import subprocess
+    forced = os.environ.get("MCALF_BENCH_MULTI_DEVICES")
+    devices = [int(x) for x in forced.split(",")] if forced else list(range(torch.cuda.device_count()))
+    if len(devices) < 2:
+        return None
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--multi-device-leg", ",".join(map(str, devices))],
+                           capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "child exited with %d" % r.returncode, "stderr_tail": r.stderr[-400:]}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": "the multi-device leg did not finish within %.0f s" % timeout_s}
+    except Exception as exc:                                 # noqa: BLE001 -- never lose the bench line to this leg
+        return {"error": repr(exc)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,12 +356,20 @@ def main():
     ap.add_argument("--no-model-leg", action="store_true", help="N=1: skip the model-output (reconstruct_spec) passes")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N=1: skip the legs over the other BASELINE configurations (B, E's 2048-row shard, E in full)")
+    ap.add_argument("--multi-device-leg", default=None,
+                    help="internal: run ONLY the one-process multi-device leg over these device entries (comma-separated) and "
+                         "print it as one JSON line (bench.py starts itself this way as a child process)")
+    ap.add_argument("--no-multi-device", action="store_true",
+                    help="N=1: skip the one-process multi-device leg (it only runs where this process sees several GPUs)")
     ap.add_argument("--only-other-configs", default=None,
                     help="diagnostic: time ONLY these legs (comma-separated: B, C, E, E2048, D) and print them as one JSON line")
     ap.add_argument("--inflight", type=int, default=1,
                     help="diagnostic: independent batches kept in flight (contexts + streams); 1 = the headline")
     args = ap.parse_args()
 
+    if args.multi_device_leg:
+        print(json.dumps(multi_device_leg([int(x) for x in args.multi_device_leg.split(",")])))
+        return
     if args.only_other_configs:
         legs = {}
         for name in args.only_other_configs.split(","):
@@ -822,6 +880,10 @@ def main():
                                    "bit_equal_host_vs_device_entry": strong_ref["host_api"]["bit_equal_to_device_entry"]}
             out["other_configs"] = other
         out["library_config"] = fit.get_config()
+        if world == 1 and config == "C" and not args.no_multi_device and not args.batch:
+            md = run_multi_device_leg()
+            # (None on a one-GPU lease; on a node whose GPUs this process all sees: ONE process driving them)
+            out["multi_device_one_process"] = md if md is not None else "skipped: this process sees one GPU"
         ll = fit.last_launch()
         out["launch"] = {"persistent": bool(ll.persistent), "grid": ll.grid, "items": ll.items,
                          "lines_per_sync": ll.lines_per_sync, "ordered_handout": bool(ll.ordered)}

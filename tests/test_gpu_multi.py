@@ -98,3 +98,21 @@ def test_get_config_names_the_knobs_and_the_environment(monkeypatch):
     with mcalf_amd.als_fitter(None, **kw) as fit:
         cfg = fit.get_config()
     assert " stream=1 " in cfg and " host_first_kb=128 " in cfg and cfg.endswith("[env: none]")
+
+
+def test_bench_one_process_multi_device_leg():
+    """`bench.py`'s one-process multi-device leg (run by the N = 1 bench in a child process wherever the process sees
+    several GPUs; here forced onto two entries of the one GPU): config D's 32768 rows through a context over the entries
+    against the first entry alone -- bit-equal, every entry used."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--multi-device-leg", "0,0"], capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["rows"] == 32768 and d["devices"] == [0, 0]
+    assert d["n1"]["devices_used"] == 1 and d["n2"]["devices_used"] == 2
+    assert d["n2"]["bit_equal_to_one_device"] and d["n2"]["ms_per_step"] > 0 and d["n2"]["speedup_vs_one_device"] > 0.5

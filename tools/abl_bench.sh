@@ -6,7 +6,7 @@ rounds=${ABL_ROUNDS:-3}
 tmp=$(mktemp)
 for r in $(seq $rounds); do
   for lib in build/abl/lib_*.so; do
-    MCALF_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 200 --warmup 20 --cpu-seconds 0 --no-host-api --no-strong-ref --no-other-configs "$@" 2>/dev/null | python -c "
+    MCALF_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 200 --warmup 20 --cpu-seconds 0 --no-host-api --no-strong-ref --no-other-configs --no-multi-device "$@" 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$lib', d['kernel_ms'], d['ms_per_step'])" >> $tmp
   done
 done

@@ -23,7 +23,7 @@ case "$recipe" in
   bench)
     cfg=${1:-C}
     timeout -k 10 500 python bench.py --config $cfg > "$out/bench_$cfg.json" 2> "$out/bench_$cfg.err"; tail -c 600 "$out/bench_$cfg.json"
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/ktrace_$cfg" --output-format csv -- python3 bench.py --config $cfg --cpu-seconds 0 --no-strong-ref --no-model-leg --no-other-configs > "$out/bench_${cfg}_under_tracer.json" 2> "$out/ktrace_$cfg.err"
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/ktrace_$cfg" --output-format csv -- python3 bench.py --config $cfg --cpu-seconds 0 --no-strong-ref --no-model-leg --no-other-configs --no-multi-device > "$out/bench_${cfg}_under_tracer.json" 2> "$out/ktrace_$cfg.err"
     find "$out/ktrace_$cfg" -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$out/bench_${cfg}_kernel_stats.csv"; head -5 "$out/bench_${cfg}_kernel_stats.csv" ;;
   profiles)
     cfg=${1:-C}; steps=50; [ "$cfg" = E ] && steps=20; [ "$cfg" = B ] && steps=100
@@ -33,7 +33,7 @@ case "$recipe" in
     timeout -k 10 200 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU -d "$out/lane_unit" --output-format csv -- build/lane_unit > "$out/lane_unit.log" 2>&1
     python3 tools/micro/lane_unit_summary.py "$out/lane_unit" "$out/lane_unit.json" | tee "$out/lane_unit.txt" ;;
   coll)
-    common="--config C --steps 200 --warmup 20 --cpu-seconds 0 --no-host-api --no-strong-ref --no-model-leg --no-other-configs"
+    common="--config C --steps 200 --warmup 20 --cpu-seconds 0 --no-host-api --no-strong-ref --no-model-leg --no-other-configs --no-multi-device"
     timeout -k 10 200 python3 bench.py $common > "$out/bench_C_no_process_group.json" 2>> "$out/coll.err"
     MCALF_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 $common > "$out/bench_C_one_rank_rccl_three_gathers.json" 2>> "$out/coll.err"
     python3 - "$out" <<'PY'
@@ -60,7 +60,7 @@ PY
     timeout -k 10 400 python3 tools/host_floor.py > "$out/host_floor.txt" 2>&1; tail -20 "$out/host_floor.txt" ;;
   ab)
     cfg=${1:-C}; steps=${2:-200}
-    ABL_ROUNDS=${ABL_ROUNDS:-3} bash tools/abl_bench.sh --config $cfg --no-model-leg --no-other-configs --steps $steps > "$out/ab_$cfg.txt" 2>&1; cat "$out/ab_$cfg.txt" ;;
+    ABL_ROUNDS=${ABL_ROUNDS:-3} bash tools/abl_bench.sh --config $cfg --no-model-leg --no-other-configs --no-multi-device --steps $steps > "$out/ab_$cfg.txt" 2>&1; cat "$out/ab_$cfg.txt" ;;
   hostgap)
     legs=${1:-B,E,E2048}
     run() {  # name, then VAR=value ...

@@ -9,7 +9,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_TRANS GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $set -d "$out/pass$i" --output-format csv -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-other-configs "$@" > "$out/pass$i.json" 2> "$out/pass$i.err" || echo "pass $i failed"
+  timeout -k 10 300 rocprofv3 --pmc $set -d "$out/pass$i" --output-format csv -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-other-configs --no-multi-device "$@" > "$out/pass$i.json" 2> "$out/pass$i.err" || echo "pass $i failed"
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections

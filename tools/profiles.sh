@@ -8,7 +8,7 @@ cfg=${1:-C}; out=${2:-gpurun_out/prof_$cfg}; steps=${3:-50}; tag=${4:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
 timeout -k 10 600 python bench.py --config $cfg --steps $steps > "$out/bench.json" 2> "$out/bench.err" || echo "bench failed"
-common="--config $cfg --steps $steps --warmup 5 --cpu-seconds 0 --no-host-api --no-strong-ref --no-model-leg --no-other-configs"
+common="--config $cfg --steps $steps --warmup 5 --cpu-seconds 0 --no-host-api --no-strong-ref --no-model-leg --no-other-configs --no-multi-device"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/ktrace" --output-format csv -- python3 bench.py $common > "$out/ktrace_bench.json" 2> "$out/ktrace.err" || echo "kernel trace failed"
 find "$out/ktrace" -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$out/kernel_stats.csv"
 i=0
