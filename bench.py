@@ -16,6 +16,10 @@ A "step" is one pass of the hot path over one batch of synthetic live points.
                    been measured and the process exits non-zero.  The N = 1 line carries the one-GPU time of the
                    same 32768 rows (`strong_scaling_reference`).
 
+The N = 1 line also carries `other_configs` (B, E's 2048-row shard, E in full, D through host pointers: each both ways with the
+path taken and a parity spot check), `library_config` (the knobs the library ran under) and -- where this process sees several
+GPUs -- `multi_device_one_process`: config D through ONE context over 1 / 2 / 4 / all visible devices (mcalf_create_multi).
+
 `value` is timed through the device-pointer entry, parameters resident in HBM when the timed region starts and
 logL left in HBM (the bench contract).  `value_host_api` is the same K steps through the host-pointer entry
 `mcalf_loglike_batch` -- H2D of P and D2H of logL inside every step, SURVEY.md section 8(d)'s definition --
