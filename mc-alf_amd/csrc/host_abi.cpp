@@ -966,7 +966,8 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
     }
     // A failure in block k leaves blocks < k in flight on both streams, reading the staging block / the caller's
     // page-locked rows and writing the caller's results: never return under them (the next call may free the
-    // staging block, the caller its arrays).  Every error below therefore leaves through `fail`.
+    // staging block, the caller its arrays).  Every error below therefore BREAKS out of the loop and is reported behind
+    // the waits for the helpers and the three streams.
     hipError_t he = hipSuccess;
     const char* what = "";
     rc = MCALF_OK;
@@ -1029,12 +1030,8 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
     const hipError_t s0 = hipStreamSynchronize(ctx->stream);
     hipError_t s1 = (nchunks > 1) ? hipStreamSynchronize(ctx->aux[0]) : hipSuccess;
     { const hipError_t s2 = hipStreamSynchronize(copy_stream); if (s1 == hipSuccess) s1 = s2; }    // (a copy no kernel waited for, after a failure)
-    if (rc != MCALF_OK) return rc;                                   // (message set by launch_range)
-    if (he != hipSuccess) return set_err(ctx, MCALF_ERR_HIP, "%s failed: %s", what, hipGetErrorString(he));
-    if (s0 != hipSuccess || s1 != hipSuccess)
-        return set_err(ctx, MCALF_ERR_HIP, "stream synchronisation failed: %s", hipGetErrorString(s0 != hipSuccess ? s0 : s1));
     const double t_w1 = trace ? now_us() : 0.0;
-    if (timeline) {
+    if (timeline) {                                       // (read and released whatever the call's outcome)
         ctx->btrace.sync_us = t_w1 - t_begin;
         for (int c = 0; c < ctx->btrace.n; ++c) {
             (void)hipEventElapsedTime(&ctx->btrace.h2d0[c], tev[3 * kMaxChunks], tev[3 * c]);
@@ -1042,7 +1039,12 @@ static int run_host_pipelined(mcalf_ctx* ctx, int mode, const double* P, int64_t
             (void)hipEventElapsedTime(&ctx->btrace.done[c], tev[3 * kMaxChunks], tev[3 * c + 2]);
         }
         for (hipEvent_t e : tev) if (e) (void)hipEventDestroy(e);
+        (void)hipGetLastError();
     }
+    if (rc != MCALF_OK) return rc;                                   // (message set by launch_range)
+    if (he != hipSuccess) return set_err(ctx, MCALF_ERR_HIP, "%s failed: %s", what, hipGetErrorString(he));
+    if (s0 != hipSuccess || s1 != hipSuccess)
+        return set_err(ctx, MCALF_ERR_HIP, "stream synchronisation failed: %s", hipGetErrorString(s0 != hipSuccess ? s0 : s1));
     if (!pin_out) std::memcpy(out_scalar, stage_out, (size_t)batch * sizeof(double));
     if (trace) {
         HostTrace& t = ctx->htrace;
