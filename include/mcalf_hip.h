@@ -148,7 +148,7 @@ int mcalf_create(const mcalf_spec* spec, mcalf_ctx** out);
  * ordinal may repeat -- two entries on one GPU are two independent sub-contexts).  The reference's large batches arise
  * inside one process (jaxns vmaps the likelihood over the live points, cli.py:274-280): the host-pointer entries of such
  * a context -- mcalf_loglike_batch, _chi2_batch, _model_batch, _onecomp_batch, _loglike_cube_batch -- cut the rows into
- * contiguous blocks (rows [batch k / n, batch (k + 1) / n) to entry k of the n entries in use; an entry gets at least 256
+ * contiguous blocks whose sizes differ by at most one (entry k of the n entries in use; an entry gets at least 256
  * rows, so small calls and the one-theta callables run on entry 0 alone), issue every device's call concurrently -- the
  * calling thread drives entry 0, a helper thread of the context each of the others -- and every device writes its block of
  * results straight into the caller's array: no collective, no device-to-device traffic.  A live point's arithmetic does

@@ -329,7 +329,11 @@ void apply_environment(mcalf_ctx* ctx);                // host_config.cpp: the e
 // ---- host_multi.cpp: one process driving several devices ---------------------------------------------------------------
 void multi_release(mcalf_ctx* ctx);                    // stops the workers, destroys the sub-contexts
 // Rows [lo, hi) of `batch` that sub-context k of n evaluates (contiguous blocks; the arithmetic of mc-alf_amd/dist.py).
-inline void multi_bounds(int64_t batch, int n, int k, int64_t* lo, int64_t* hi) { *lo = batch * k / n; *hi = batch * (k + 1) / n; }
+inline void multi_bounds(int64_t batch, int n, int k, int64_t* lo, int64_t* hi) {     // (shard_bounds of dist.py: sizes differ by at most one)
+    const int64_t base = batch / n, extra = batch % n;
+    *lo = (int64_t)k * base + std::min<int64_t>(k, extra);
+    *hi = *lo + base + (k < extra ? 1 : 0);
+}
 int multi_active(const mcalf_ctx* ctx, int64_t batch);  // sub-contexts a batch of this size is cut over (>= 1)
 // fn(sub, k, lo, hi) on every active sub-context concurrently (sub 0 on the calling thread); first error wins.
 int multi_run(mcalf_ctx* ctx, int64_t batch, WorkFn fn, void* arg);      // (fn's `who` is the sub-context)

@@ -3,8 +3,8 @@
 // The reference's large batches arise inside one Python process (jaxns vmaps the likelihood over the live points:
 // cli.py:274-280), and its only parallelism is data parallelism over live points (cli.py:110).  A multi-device context
 // is that for the host-pointer entries: one complete sub-context per device entry (spectrum replicated), contiguous
-// row blocks of the caller's batch (the arithmetic of mc-alf_amd/dist.py: rows [batch k / n, batch (k + 1) / n) go to
-// sub-context k), every device's call -- streaming launch, row-block pipeline, zero-copy small call, whatever its
+// row blocks of the caller's batch (shard_bounds of mc-alf_amd/dist.py: block sizes differ by at most one, the first
+// batch % n sub-contexts take the longer ones), every device's call -- streaming launch, row-block pipeline, zero-copy small call, whatever its
 // shard's size selects -- issued concurrently, each writing its block of results straight into the caller's array.
 // No collective: the results land in host memory, where the caller wants them.  Because a live point's arithmetic does
 // not depend on the shard, the batch equals the single-device result bit for bit.

@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _shards(batch, n):
-    return [(batch * k // n, batch * (k + 1) // n) for k in range(n)]
+    from mcalf_amd import dist as mdist
+    return [mdist.shard_bounds(batch, n, k) for k in range(n)]
 
 
 @pytest.mark.parametrize("cfg,rows,devices", [("C", 4096, [0, 0]), ("C", 4096, [0, 0, 0]), ("E", 2048, [0, 0]), ("E", 1000, [0, 0, 0])])
