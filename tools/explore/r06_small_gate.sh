@@ -1,3 +1,5 @@
+# NOTE: the launch-before-copy variant this script measured (MCALF_SMALL_GATE) was REMOVED from the source after the run (slower:
+# profiles/r06_small_call_gate_experiment.txt; commit "Small host calls launch before they copy their rows" has it); kept as the record of how it was measured.
 # GPU box: config B's step through host pointers with and without the gated launch (launch first, copy afterwards), interleaved.
 cd "$GRAFT_REPO_ROOT"; out=gpurun_out/r06; mkdir -p $out; : > $out/small_gate.txt
 for rep in 1 2 3; do
