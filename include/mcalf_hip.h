@@ -156,6 +156,12 @@ int mcalf_create(const mcalf_spec* spec, mcalf_ctx** out);
  * _set_cu_mask / _reserve apply to every entry, mcalf_set_resident to entry 0; the *_device entries, the profile brackets,
  * the broker and the mcalf_comm_* family need a single-device context (MCALF_ERR_INVALID). */
 int mcalf_create_multi(const mcalf_spec* spec, const int32_t* devices, int32_t ndevices, mcalf_ctx** out);
+/* How a multi-device context of `nentries` device entries cuts a batch: *entries_used = the entries that take part (every one
+ * of them gets at least 256 rows), [*lo, *hi) = the rows of entry k (empty for an entry that sits the call out).  Pure host
+ * arithmetic, no device needed -- the functions mcalf_create_multi's contexts use; block sizes differ by at most one, the
+ * first batch % entries_used entries take the longer ones (mc-alf_amd/dist.py::shard_bounds, the split of the one-process-
+ * per-GPU form). */
+int mcalf_shard_bounds(int64_t batch, int32_t nentries, int32_t k, int32_t* entries_used, int64_t* lo, int64_t* hi);
 void mcalf_destroy(mcalf_ctx* ctx);
 int mcalf_info(const mcalf_ctx* ctx, mcalf_info_t* info);
 const char* mcalf_last_error(const mcalf_ctx* ctx);

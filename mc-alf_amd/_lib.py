@@ -121,6 +121,7 @@ _CTX = C.c_void_p
 SYMBOLS = {
     "mcalf_create": (C.c_int, [C.POINTER(mcalf_spec), C.POINTER(_CTX)]),
     "mcalf_create_multi": (C.c_int, [C.POINTER(mcalf_spec), C.POINTER(C.c_int32), C.c_int32, C.POINTER(_CTX)]),
+    "mcalf_shard_bounds": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mcalf_destroy": (None, [_CTX]),
     "mcalf_get_config": (C.c_int, [_CTX, C.c_char_p, C.c_int64]),
     "mcalf_last_launch_sub": (C.c_int, [_CTX, C.c_int32, C.POINTER(mcalf_launch_info_t)]),

@@ -37,7 +37,7 @@ void multi_release(mcalf_ctx* ctx) {
 
 int multi_active(const mcalf_ctx* ctx, int64_t batch) {
     const int64_t n = std::min<int64_t>((int64_t)ctx->subs.size(), batch / kMultiMinRows);
-    return (int)std::max<int64_t>(1, n);
+    return (int)std::max<int64_t>(1, n);                  // (mcalf_shard_bounds states the same rule for callers and tests)
 }
 
 int multi_run(mcalf_ctx* ctx, int64_t batch, WorkFn fn, void* arg) {
@@ -101,6 +101,17 @@ extern "C" int mcalf_create_multi(const mcalf_spec* spec, const int32_t* devices
         ctx->pool->workers.push_back(std::move(w));
     }
     *out = ctx;
+    return MCALF_OK;
+}
+
+extern "C" int mcalf_shard_bounds(int64_t batch, int32_t nentries, int32_t k, int32_t* entries_used, int64_t* lo, int64_t* hi) {
+    if (batch < 0 || nentries < 1 || nentries > kMaxDevices || !entries_used || !lo || !hi)
+        return set_err(nullptr, MCALF_ERR_INVALID, "mcalf_shard_bounds: batch >= 0, 1 <= nentries <= %d, non-NULL outputs", kMaxDevices);
+    const int n = (int)std::max<int64_t>(1, std::min<int64_t>(nentries, batch / kMultiMinRows));      // (multi_active)
+    *entries_used = n;
+    if (k < 0 || k >= nentries) return set_err(nullptr, MCALF_ERR_INVALID, "mcalf_shard_bounds: entry %d of %d", k, nentries);
+    if (k >= n) { *lo = *hi = batch; return MCALF_OK; }                                                // (an entry that sits this call out)
+    multi_bounds(batch, n, k, lo, hi);
     return MCALF_OK;
 }
 

@@ -139,3 +139,33 @@ def test_crii_overrides_are_the_reference_s_own_constants(nodev):
     assert [(d["wrest"], d["f"], d["gamma"]) for d in raw.linepars] == db
     with pytest.raises(ValueError, match="triples"):
         mcalf_amd.als_fitter(None, [[8220.0, 8270.0]], names, [1, 1], spectrum=kw["spectrum"], linepars=db[:2], zrange=[2.99, 3.01])
+
+
+def test_multi_device_sharding_is_dist_shard_bounds():
+    """mcalf_shard_bounds (pure host arithmetic; what a mcalf_create_multi context cuts its batches with): the entries in use
+    cover the batch exactly once with contiguous blocks whose sizes differ by at most one -- the split of
+    mc-alf_amd/dist.py::shard_bounds, i.e. of the one-process-per-GPU form -- every entry in use gets at least 256 rows, and
+    entries beyond those sit the call out."""
+    import ctypes as C
+    from mcalf_amd import _lib
+    from mcalf_amd import dist as mdist
+    lib = _lib.load()
+    used, lo, hi = C.c_int32(), C.c_int64(), C.c_int64()
+    for nent in (1, 2, 3, 8, 16):
+        for batch in (0, 1, 255, 256, 511, 512, 1000, 4096, 4097, 16384, 32768, 100003):
+            rows = []
+            for k in range(nent):
+                assert lib.mcalf_shard_bounds(batch, nent, k, C.byref(used), C.byref(lo), C.byref(hi)) == 0
+                n = used.value
+                assert n == max(1, min(nent, batch // 256))
+                if k < n:
+                    assert (lo.value, hi.value) == mdist.shard_bounds(batch, n, k)
+                    assert n == 1 or hi.value - lo.value >= 256
+                    rows += list(range(lo.value, hi.value)) if batch <= 5000 else [lo.value, hi.value]
+                else:
+                    assert lo.value == hi.value == batch
+            if batch <= 5000:
+                assert rows == list(range(batch))
+    assert lib.mcalf_shard_bounds(10, 0, 0, C.byref(used), C.byref(lo), C.byref(hi)) == -1
+    assert lib.mcalf_shard_bounds(10, 2, 2, C.byref(used), C.byref(lo), C.byref(hi)) == -1
+    assert lib.mcalf_shard_bounds(10, 2, 0, None, None, None) == -1
