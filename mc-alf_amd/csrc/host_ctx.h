@@ -58,7 +58,7 @@ struct HostWorker {
         unsigned seen = 0;
         for (;;) {
             bool got = false;
-            for (int i = 0; i < 40000 && !got; ++i) {          // ~0.2 ms of looking before the thread gives the core up
+            for (int i = 0; i < 40000 && !got; ++i) {          // 40000 pause instructions (~1 ms) of looking before the thread gives the core up
                 got = posted.load(std::memory_order_acquire) != seen;
                 if (!got) __builtin_ia32_pause();
             }
