@@ -247,6 +247,11 @@ def config_leg(config, rows=None, steps=20, device=0, parity_rows=64):
         ms_dev = median_pass_ms(dev_step, steps, sync)
         logl_dev = out.cpu().numpy().copy()
         ll_dev = fit.last_launch()
+
+        def dev_sync_step():                              # the floor of ANY synchronous step: resident inputs, nothing copied
+            dev_step()
+            stream.synchronize()
+        ms_dev_sync = median_pass_ms(dev_sync_step, steps, sync)
         out_h = np.empty(rows)
         fit.loglike_batch(P, out=out_h)
         fit.loglike_batch(P, out=out_h)
@@ -267,7 +272,9 @@ def config_leg(config, rows=None, steps=20, device=0, parity_rows=64):
                 "ms_per_step_device_resident": ms_dev, "value_device_resident": comp_pix / (ms_dev * 1e-3),
                 "ms_per_step_host_api": ms_host, "value_host_api": comp_pix / (ms_host * 1e-3),
                 "ms_per_step_host_api_pinned": ms_pin,
+                "ms_per_step_device_entry_synchronised_every_step": ms_dev_sync,
                 "host_over_device": ms_host / ms_dev, "host_over_device_pinned": ms_pin / ms_dev,
+                "host_over_synchronous_floor": ms_host / ms_dev_sync,
                 "path_host_api": PATH_NAME.get(llh.path, str(llh.path)), "row_blocks_host_api": llh.row_blocks,
                 "device_launch": {"persistent": bool(ll_dev.persistent), "grid": ll_dev.grid, "items": ll_dev.items},
                 "bit_equal_host_vs_device_entry": bool(np.array_equal(out_h, logl_dev) and np.array_equal(out_pin, logl_dev)),
